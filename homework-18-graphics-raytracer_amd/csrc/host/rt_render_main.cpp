@@ -1,0 +1,72 @@
+/*
+ * rt_render — command-line driver: the reference's main() (src/main.rs:809-1115)
+ * with the rayon render loop replaced by one call across the C ABI.
+ *
+ *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png]
+ *
+ * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).
+ * Host keeps: scene build + OBJ import, post_process, sRGB/u8 encode, PNG write.
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/rt_amd.h"
+#include "../../../include/rt_host.h"
+
+int main(int argc, char **argv) {
+    uint32_t width = 1280, height = 960;
+    int32_t depth = 5;
+    const char *obj = "dodecahedron.obj";
+    const char *out = "./out.png";
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--width")) width = (uint32_t)atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--height")) height = (uint32_t)atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--depth")) depth = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--obj")) obj = argv[i + 1];
+        else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    rt_world *world = rt_world_new();
+    if (!world || rt_world_build_reference_scene(world, obj) != RT_OK) {
+        fprintf(stderr, "scene build failed: %s\n", rt_host_last_error());
+        return 1;
+    }
+    rt_scene_desc desc;
+    rt_world_desc(world, &desc);
+    rt_camera camera;
+    rt_reference_camera(&camera);
+    rt_frame frame;
+    rt_frame_full(width, height, depth, &frame);
+
+    rt_scene *scene = nullptr;
+    if (rt_scene_create(&desc, &scene) != RT_OK) {
+        fprintf(stderr, "rt_scene_create failed: %s\n", rt_last_error());
+        return 1;
+    }
+    std::vector<float> img((size_t)width * height * 3);
+    unsigned long long casts = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if (rt_render_whitted_host(scene, &camera, &frame, img.data(), &casts) != RT_OK) {
+        fprintf(stderr, "rt_render_whitted_host failed: %s\n", rt_last_error());
+        return 1;
+    }
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    /* the reference prints pixels as "rays" and divides by whole milliseconds (panics under 1 ms, main.rs:1111) */
+    const unsigned long long pixels = (unsigned long long)width * height;
+    printf("%llu rays in %.3f ms (%.0f rays/s); %llu casts (%.2f per pixel, %.1f Mcasts/s incl. copies)\n", pixels, ms,
+           ms > 0 ? pixels * 1000.0 / ms : 0.0, casts, (double)casts / (double)pixels, ms > 0 ? casts / ms / 1000.0 : 0.0);
+
+    rt_post_process(img.data(), (size_t)width * height);
+    std::vector<uint8_t> rgb8(img.size());
+    rt_encode_srgb8(img.data(), img.size(), rgb8.data());
+    if (rt_write_png(out, rgb8.data(), width, height) != RT_OK) {
+        fprintf(stderr, "rt_write_png failed: %s\n", rt_host_last_error());
+        return 1;
+    }
+    rt_scene_destroy(scene);
+    rt_world_free(world);
+    return 0;
+}

@@ -1,0 +1,308 @@
+/*
+ * rt_api.hip — implementation of the C ABI in include/rt_amd.h.
+ *
+ * Host-side plumbing only: argument validation, the one-time scene upload
+ * (with the per-primitive precompute described in rt_device_scene.h), the
+ * per-frame camera basis (Camera::shoot's ray-independent part, main.rs:85-92)
+ * and stream-ordered kernel launches.  There is NO CPU rendering fallback: if
+ * the HIP runtime or a device is missing every render entry point fails with
+ * RT_ERR_NO_DEVICE / RT_ERR_HIP.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_device_scene.h"
+#include "rt_kernels.h"
+#include "rt_vec.h"
+
+namespace rt {
+void math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
+}
+
+struct rt_scene {
+    int device;
+    void *d_blob; /* one allocation holding every array */
+    rt::KernelScene ks;
+};
+
+static thread_local std::string g_error;
+static int g_variant = -1;
+
+static int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+static int fail_hip(const char *what, hipError_t e) {
+    g_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? RT_ERR_NO_DEVICE
+           : (e == hipErrorOutOfMemory)                           ? RT_ERR_OUT_OF_MEMORY
+                                                                  : RT_ERR_HIP;
+}
+#define RT_HIP(call)                                          \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return fail_hip(#call, e_);     \
+    } while (0)
+
+static int current_variant() {
+    if (g_variant < 0) {
+        const char *v = getenv("RT_AMD_VARIANT");
+        g_variant = (v && *v) ? atoi(v) : RT_VARIANT_SGPR;
+        if (g_variant < 0 || g_variant > 1) g_variant = RT_VARIANT_SGPR;
+    }
+    return g_variant;
+}
+
+static bool frame_ok(const rt_frame *f) {
+    return f && f->width > 0 && f->height > 0 && f->y_step >= 1 && f->x0 < f->x1 && f->y0 < f->y1 && f->x1 <= f->width &&
+           f->y1 <= f->height;
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip("hipGetDeviceCount", e);
+    return n;
+}
+
+int rt_set_device(int device) {
+    RT_HIP(hipSetDevice(device));
+    return RT_OK;
+}
+
+int rt_set_variant(int variant) {
+    if (variant < 0 || variant > 1) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: variant must be 0 or 1");
+    g_variant = variant;
+    return RT_OK;
+}
+int rt_get_variant(void) { return current_variant(); }
+
+uint32_t rt_frame_rows(const rt_frame *f) {
+    if (!frame_ok(f)) return 0;
+    return (f->y1 - f->y0 + f->y_step - 1) / f->y_step;
+}
+uint64_t rt_frame_pixels(const rt_frame *f) {
+    if (!frame_ok(f)) return 0;
+    return (uint64_t)rt_frame_rows(f) * (uint64_t)(f->x1 - f->x0);
+}
+
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out_scene = nullptr;
+    if ((desc->n_triangles && !desc->triangles) || (desc->n_spheres && !desc->spheres) || (desc->n_materials && !desc->materials) ||
+        (desc->n_lights && !desc->lights))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null array with non-zero count");
+    if ((uint64_t)desc->n_triangles + desc->n_spheres >= 0x1fffffffull)
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many primitives");
+    for (uint32_t i = 0; i < desc->n_triangles; ++i)
+        if (desc->triangles[i].object_index >= desc->n_materials)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: triangle object_index out of range");
+    for (uint32_t i = 0; i < desc->n_spheres; ++i)
+        if (desc->spheres[i].object_index >= desc->n_materials)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: sphere object_index out of range");
+    for (uint32_t i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].kind > RT_LIGHT_POINT) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: unknown light kind");
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        if (desc->materials[i].diffuse_fn > RT_DIFFUSE_STRIPE_SUM || desc->materials[i].normal_fn > RT_NORMAL_WAVE_U)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: unknown material function");
+
+    using rt::V3;
+    std::vector<rt::DevTri> tris(desc->n_triangles);
+    std::vector<rt::DevTriAttr> attrs(desc->n_triangles);
+    for (uint32_t i = 0; i < desc->n_triangles; ++i) {
+        const rt_triangle &s = desc->triangles[i];
+        rt::DevTri &t = tris[i];
+        rt::DevTriAttr &a = attrs[i];
+        memset(&t, 0, sizeof t);
+        memset(&a, 0, sizeof a);
+        const V3 v0 = rt::v3p(s.vertices[0].position), v1 = rt::v3p(s.vertices[1].position), v2 = rt::v3p(s.vertices[2].position);
+        /* Triangle::face_normal, primitives.rs:36-42 */
+        const V3 n = rt::normalize(rt::cross(v1 - v0, v2 - v1));
+        t.n[0] = n.x; t.n[1] = n.y; t.n[2] = n.z;
+        t.d = rt::dot(n, v0); /* main.rs:203 */
+        t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
+        t.v1[0] = v1.x; t.v1[1] = v1.y; t.v1[2] = v1.z;
+        t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z;
+        t.obj = s.object_index;
+        const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0; /* main.rs:219-221 */
+        t.e0[0] = e0.x; t.e0[1] = e0.y; t.e0[2] = e0.z;
+        t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
+        t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+        t.area = rt::dot(rt::cross(v1 - v0, v2 - v0), n); /* main.rs:235 */
+        for (int k = 0; k < 3; ++k) {
+            a.n0[k] = s.vertices[0].normal[k];
+            a.n1[k] = s.vertices[1].normal[k];
+            a.n2[k] = s.vertices[2].normal[k];
+        }
+        a.uv0x = s.vertices[0].uv[0]; a.uv0y = s.vertices[0].uv[1];
+        a.uv1x = s.vertices[1].uv[0]; a.uv1y = s.vertices[1].uv[1];
+        a.uv2x = s.vertices[2].uv[0]; a.uv2y = s.vertices[2].uv[1];
+    }
+    std::vector<rt::DevSphere> spheres(desc->n_spheres);
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const rt_sphere &s = desc->spheres[i];
+        rt::DevSphere &d = spheres[i];
+        memset(&d, 0, sizeof d);
+        d.c[0] = s.center[0]; d.c[1] = s.center[1]; d.c[2] = s.center[2];
+        d.radius = s.radius;
+        d.r2 = s.radius * s.radius; /* radius.powi(2), main.rs:272 */
+        d.obj = s.object_index;
+    }
+
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t off_tris = 0;
+    const size_t off_attrs = off_tris + up(tris.size() * sizeof(rt::DevTri));
+    const size_t off_spheres = off_attrs + up(attrs.size() * sizeof(rt::DevTriAttr));
+    const size_t off_mats = off_spheres + up(spheres.size() * sizeof(rt::DevSphere));
+    const size_t off_lights = off_mats + up(desc->n_materials * sizeof(rt_material));
+    const size_t total = off_lights + up(desc->n_lights * sizeof(rt_light)) + 256;
+
+    std::vector<unsigned char> blob(total, 0);
+    if (!tris.empty()) memcpy(&blob[off_tris], tris.data(), tris.size() * sizeof(rt::DevTri));
+    if (!attrs.empty()) memcpy(&blob[off_attrs], attrs.data(), attrs.size() * sizeof(rt::DevTriAttr));
+    if (!spheres.empty()) memcpy(&blob[off_spheres], spheres.data(), spheres.size() * sizeof(rt::DevSphere));
+    if (desc->n_materials) memcpy(&blob[off_mats], desc->materials, desc->n_materials * sizeof(rt_material));
+    if (desc->n_lights) memcpy(&blob[off_lights], desc->lights, desc->n_lights * sizeof(rt_light));
+
+    rt_scene *sc = new (std::nothrow) rt_scene();
+    if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
+    sc->d_blob = nullptr;
+    hipError_t e = hipGetDevice(&sc->device);
+    if (e == hipSuccess) e = hipMalloc(&sc->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(sc->d_blob, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (sc->d_blob) (void)hipFree(sc->d_blob);
+        delete sc;
+        return fail_hip("rt_scene_create: device upload", e);
+    }
+    unsigned char *base = static_cast<unsigned char *>(sc->d_blob);
+    sc->ks.tris = reinterpret_cast<const rt::DevTri *>(base + off_tris);
+    sc->ks.attrs = reinterpret_cast<const rt::DevTriAttr *>(base + off_attrs);
+    sc->ks.spheres = reinterpret_cast<const rt::DevSphere *>(base + off_spheres);
+    sc->ks.materials = reinterpret_cast<const rt_material *>(base + off_mats);
+    sc->ks.lights = reinterpret_cast<const rt_light *>(base + off_lights);
+    sc->ks.n_triangles = desc->n_triangles;
+    sc->ks.n_spheres = desc->n_spheres;
+    sc->ks.n_materials = desc->n_materials;
+    sc->ks.n_lights = desc->n_lights;
+    *out_scene = sc;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return RT_OK;
+    hipError_t e = hipSuccess;
+    if (scene->d_blob) e = hipFree(scene->d_blob);
+    delete scene;
+    if (e != hipSuccess) return fail_hip("rt_scene_destroy: hipFree", e);
+    return RT_OK;
+}
+
+static int make_kernel_frame(const rt_camera *camera, const rt_frame *frame, rt::KernelFrame *kf) {
+    if (!camera) return fail(RT_ERR_INVALID_ARGUMENT, "render: null camera");
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "render: bad frame (need 0 <= x0 < x1 <= width, 0 <= y0 < y1 <= height, y_step >= 1)");
+    if (frame->max_depth > RT_MAX_DEPTH) return fail(RT_ERR_UNSUPPORTED, "render: max_depth above RT_MAX_DEPTH");
+    using rt::V3;
+    /* Camera::shoot, main.rs:85-92: the ray-independent part */
+    const V3 toward = rt::normalize(rt::v3p(camera->toward));
+    const V3 right = rt::normalize(rt::cross(toward, rt::v3p(camera->up)));
+    const V3 up = rt::normalize(rt::cross(right, toward));
+    const float th = rtdm::tanf(camera->fovy / 2.0f);
+    const V3 x = th * right;
+    const V3 y = th * up;
+    const V3 origin = rt::v3p(camera->center) + toward * camera->near;
+    kf->cols = frame->x1 - frame->x0;
+    kf->rows = rt_frame_rows(frame);
+    kf->x0 = frame->x0;
+    kf->y0 = frame->y0;
+    kf->y_step = frame->y_step;
+    kf->max_depth = frame->max_depth;
+    kf->half_height = (float)frame->height / 2.0f;
+    kf->half_width = (float)frame->width / 2.0f;
+    kf->height_f = (float)frame->height;
+    kf->cam_origin[0] = origin.x; kf->cam_origin[1] = origin.y; kf->cam_origin[2] = origin.z;
+    kf->cam_x[0] = x.x; kf->cam_x[1] = x.y; kf->cam_x[2] = x.z;
+    kf->cam_y[0] = y.x; kf->cam_y[1] = y.y; kf->cam_y[2] = y.z;
+    kf->cam_toward[0] = toward.x; kf->cam_toward[1] = toward.y; kf->cam_toward[2] = toward.z;
+    return RT_OK;
+}
+
+int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float *d_rgb,
+                      unsigned long long *d_ray_count, void *hip_stream) {
+    if (!scene || !d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_whitted: null argument");
+    rt::KernelFrame kf;
+    int rc = make_kernel_frame(camera, frame, &kf);
+    if (rc != RT_OK) return rc;
+    hipError_t e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, static_cast<hipStream_t>(hip_stream), current_variant());
+    if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
+    return RT_OK;
+}
+
+int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float *h_rgb,
+                           unsigned long long *h_ray_count) {
+    if (!scene || !h_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_whitted_host: null argument");
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_whitted_host: bad frame");
+    const size_t bytes = (size_t)rt_frame_pixels(frame) * 3 * sizeof(float);
+    float *d_rgb = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_rgb), bytes));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long));
+    int rc = RT_OK;
+    if (e == hipSuccess) {
+        rc = rt_render_whitted(scene, camera, frame, d_rgb, d_cnt, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(h_rgb, d_rgb, bytes, hipMemcpyDeviceToHost);
+            unsigned long long cnt = 0;
+            if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && h_ray_count) *h_ray_count = cnt;
+        }
+    }
+    (void)hipFree(d_rgb);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail_hip("rt_render_whitted_host", e);
+    return RT_OK;
+}
+
+int rt_math_eval_host(int op, const float *x, const float *y, float *out, size_t n) {
+    if (!x || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_math_eval_host: null argument");
+    rt::math_eval_host(op, x, y, out, n);
+    return RT_OK;
+}
+
+int rt_math_eval_device(int op, const float *h_x, const float *h_y, float *h_out, size_t n) {
+    if (!h_x || !h_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_math_eval_device: null argument");
+    if (n == 0) return RT_OK;
+    float *d_x = nullptr, *d_y = nullptr, *d_o = nullptr;
+    const size_t bytes = n * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_x), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_y), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_o), bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_x, h_x, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = h_y ? hipMemcpy(d_y, h_y, bytes, hipMemcpyHostToDevice) : hipMemset(d_y, 0, bytes);
+    if (e == hipSuccess) e = rt::launch_math_eval(op, d_x, d_y, d_o, n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_o, bytes, hipMemcpyDeviceToHost);
+    if (d_x) (void)hipFree(d_x);
+    if (d_y) (void)hipFree(d_y);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return fail_hip("rt_math_eval_device", e);
+    return RT_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,56 @@
+/*
+ * rt_device_scene.h — device-resident scene layout.
+ *
+ * rt_scene_create() converts the ABI arrays (include/rt_amd.h) into these
+ * records once.  Everything precomputed here is a pure function of one
+ * primitive's vertices, evaluated with the reference's own operation order, so
+ * it is bit-identical to what the reference recomputes per ray:
+ *
+ *   n   = normalize((v1-v0) x (v2-v1))       primitives.rs:36-42, used at main.rs:184,202
+ *   d   = n . v0                             main.rs:203
+ *   e0  = v2-v1, e1 = v0-v2, e2 = v1-v0      main.rs:219-221
+ *   area = ((v1-v0) x (v2-v0)) . n           main.rs:235
+ *   r2  = radius * radius                    main.rs:272 (powi(2))
+ *
+ * DevTri is 96 bytes = three 32-byte groups; the intersection loop indexes it
+ * with a wave-uniform index, so the compiler fetches it with scalar loads
+ * (s_load_dwordx8) into SGPRs, or the kernel stages it in LDS (see
+ * rt_kernels.hip) — either way one fetch serves all 64 lanes.
+ */
+#ifndef RT_DEVICE_SCENE_H
+#define RT_DEVICE_SCENE_H
+
+#include <stdint.h>
+
+namespace rt {
+
+struct alignas(32) DevTri {
+    float n[3];  float d;          /* plane */
+    float v0[3]; uint32_t obj;
+    float v1[3]; float area;       /* area of the whole triangle (barycentric denominator) */
+    float v2[3]; float pad0;
+    float e0[3]; float pad1;       /* v2 - v1 */
+    float e1[3]; float pad2;       /* v0 - v2 */
+    float e2[3]; float pad3;       /* v1 - v0 */
+    float pad4[4];
+};
+static_assert(sizeof(DevTri) == 128, "DevTri must be 128 bytes");
+
+/* per-vertex attributes, only read for the winning primitive of a cast */
+struct alignas(16) DevTriAttr {
+    float n0[3]; float uv0x;
+    float n1[3]; float uv0y;
+    float n2[3]; float uv1x;
+    float uv1y, uv2x, uv2y, pad;
+};
+static_assert(sizeof(DevTriAttr) == 64, "DevTriAttr must be 64 bytes");
+
+struct alignas(32) DevSphere {
+    float c[3]; float radius;
+    float r2;   uint32_t obj; float pad[2];
+};
+static_assert(sizeof(DevSphere) == 32, "DevSphere must be 32 bytes");
+
+} /* namespace rt */
+
+#endif

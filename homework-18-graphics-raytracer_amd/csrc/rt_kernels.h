@@ -1,0 +1,56 @@
+/*
+ * rt_kernels.h — interface between the C-ABI layer (rt_api.hip) and the kernels
+ * (rt_kernels.hip).  Internal; the public boundary is include/rt_amd.h.
+ */
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_device_scene.h"
+
+#define RT_BLOCK_THREADS 256
+#define RT_LDS_SCENE_LIMIT (96u * 1024u) /* triangle records staged in LDS up to this many bytes */
+
+/* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant) */
+#define RT_VARIANT_SGPR 0 /* triangle records fetched with wave-uniform scalar loads */
+#define RT_VARIANT_LDS 1  /* triangle records staged in LDS once per workgroup     */
+
+namespace rt {
+
+/* device pointers + counts, passed by value as kernel arguments (lands in SGPRs) */
+struct KernelScene {
+    const DevTri *tris;
+    const DevTriAttr *attrs;
+    const DevSphere *spheres;
+    const rt_material *materials;
+    const rt_light *lights;
+    uint32_t n_triangles, n_spheres, n_materials, n_lights;
+};
+
+/* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),
+ * hoisted to the host: it is the same for every ray */
+struct KernelFrame {
+    uint32_t cols, rows;     /* tile size in pixels */
+    uint32_t x0, y0, y_step; /* tile origin and row stride in the image */
+    int32_t max_depth;
+    float half_height;       /* height as f32 / 2.0   (main.rs:1094) */
+    float half_width;        /* width as f32 / 2.0    (main.rs:1095) */
+    float height_f;          /* height as f32 */
+    float cam_origin[3];     /* center + toward * near */
+    float cam_x[3];          /* tan(fovy/2) * right */
+    float cam_y[3];          /* tan(fovy/2) * up' */
+    float cam_toward[3];     /* normalize(toward) */
+};
+
+hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                          hipStream_t stream, int variant);
+
+/* diagnostics: evaluate rt_detmath on the device (op codes = rt_math_op) */
+hipError_t launch_math_eval(int op, const float *d_x, const float *d_y, float *d_out, size_t n, hipStream_t stream);
+
+} /* namespace rt */
+
+#endif

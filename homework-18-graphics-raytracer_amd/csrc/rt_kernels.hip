@@ -1,0 +1,599 @@
+/*
+ * rt_kernels.hip — the render path as hand-written HIP for gfx950 (MI355X).
+ *
+ * Replaces the rayon closure at src/main.rs:1090-1104 (camera.shoot ->
+ * world.ray_trace) with one kernel:
+ *
+ *   - one work-item per primary ray, a wave = an 8x8 pixel tile;
+ *   - World::cast (main.rs:180-326) is a wave-convergent brute-force loop: the
+ *     primitive index is wave-uniform, so each triangle record is fetched ONCE
+ *     per wave (scalar loads into SGPRs, or an LDS broadcast read in the LDS
+ *     variant) and tested by all 64 lanes; only the per-primitive accept
+ *     predicate diverges;
+ *   - the recursion of World::ray_trace (main.rs:466-519), get_shade's light
+ *     loop (407-464) and get_refract's bounce loop (343-405) are unrolled into
+ *     a per-lane state machine whose only expensive step is "cast one ray":
+ *     every trip of the outer loop, every live lane casts whatever ray its own
+ *     state needs next (primary, shadow, reflection, inside-glass bounce,
+ *     escape) through the SAME convergent intersection loop, then advances its
+ *     state with cheap divergent code.  A wave ballot ends the loop;
+ *   - the post-order combine `shade*sc + reflection*rc + refraction*fc`
+ *     (main.rs:516-518) keeps its association through an explicit per-lane
+ *     frame stack (one frame per node that has children), so results are
+ *     bit-identical to the recursive form.  Subtrees are pure, so the kernel
+ *     is free to evaluate get_refract's casts before descending into the
+ *     reflection child; that lets a frame hold the ready-made escape ray
+ *     instead of the whole hit.
+ *
+ * Floating point: IEEE binary32 with no contraction (-ffp-contract=off),
+ * correctly rounded divide/sqrt (hipcc default), denormals kept; the
+ * transcendentals are rt_detmath.h.  See DESIGN.md "Numerics".
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_device_scene.h"
+#include "rt_shade.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+/* ---- ray / hit records ------------------------------------------------------ */
+
+enum : uint32_t { FACE_FRONT = 0u, FACE_BACK = 1u, FACE_BOTH = 2u }; /* main.rs:52-57 */
+
+/* Packed exclusion (main.rs:77-81): 0 = None, else
+ *   bit 31 = Some, bits 29..30 = face direction, bits 0..28 = primitive id.
+ * Primitive ids: triangle i -> i, sphere i -> n_triangles + i (PrimitiveIndex, primitives.rs:31-34). */
+__device__ __forceinline__ uint32_t pack_excl(uint32_t prim, uint32_t face) { return 0x80000000u | (face << 29) | prim; }
+
+struct Ray {
+    V3 o, d;
+    uint32_t mode; /* FaceDirection of the ray (culling mode) */
+    uint32_t excl; /* packed exclusion */
+};
+
+struct CastResult {
+    float t;       /* travel distance of the nearest hit */
+    int32_t prim;  /* -1 = miss */
+    uint32_t bf;   /* backface flag of the hit */
+    float a0, a1, a2; /* triangle hits: the three signed areas (main.rs:218-222) */
+};
+
+/* World::cast, main.rs:180-326.  Convergent: `i` is wave-uniform. */
+template <bool USE_LDS>
+__device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *__restrict__ lds_tris, const Ray &ray) {
+    CastResult best;
+    best.prim = -1;
+    best.t = 0.0f;
+    best.bf = 0u;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    bool have = false;
+
+    const bool cull_back = ray.mode == FACE_FRONT;  /* skip backfaces  (main.rs:185) */
+    const bool cull_front = ray.mode == FACE_BACK;  /* skip frontfaces (main.rs:186) */
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+
+    const uint32_t nt = sc.n_triangles;
+    const DevTri *__restrict__ tris = USE_LDS ? lds_tris : sc.tris;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const DevTri &T = tris[i];
+        const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+        const float nd = dot(n, ray.d);
+        const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
+        if (bf ? cull_back : cull_front) continue;
+        if (ex_some && ex_prim == i) { /* main.rs:190-200 */
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        const float t = (T.d - dot(n, ray.o)) / nd; /* main.rs:203-204 */
+        if (t <= 0.0f) continue;                     /* NaN passes, as in the reference */
+        const V3 p = ray.o + ray.d * t;
+        const V3 v0 = v3(T.v0[0], T.v0[1], T.v0[2]);
+        const V3 v1 = v3(T.v1[0], T.v1[1], T.v1[2]);
+        const V3 v2 = v3(T.v2[0], T.v2[1], T.v2[2]);
+        const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v1), n);
+        const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v2), n);
+        const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v0), n);
+        if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue; /* NaN areas pass (main.rs:224) */
+        if (have && best.t < t) continue;                  /* ties: the later primitive wins */
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)i;
+        best.bf = bf ? 1u : 0u;
+        best.a0 = a0; best.a1 = a1; best.a2 = a2;
+    }
+
+    const uint32_t ns = sc.n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
+        const DevSphere &S = sc.spheres[i];
+        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
+        const V3 disp = c - ray.o;
+        const float lsd = magnitude(cross(disp, ray.d));
+        if (lsd > S.radius) continue;
+        const float tc = dot(ray.d, disp);
+        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
+        float t;
+        bool bf;
+        if (ray.mode == FACE_FRONT) { t = tc - k; bf = false; }
+        else if (ray.mode == FACE_BACK) { t = tc + k; bf = true; }
+        else if (tc < k) { t = tc + k; bf = true; }
+        else { t = tc - k; bf = false; }
+        if (t <= 0.0f) continue;
+        if (ex_some && ex_prim == nt + i) {
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        if (have && best.t < t) continue;
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)(nt + i);
+        best.bf = bf ? 1u : 0u;
+    }
+    return best;
+}
+
+/* What the state machine keeps of a Hit (main.rs:139-147). */
+struct HitGeom {
+    V3 pos, normal;
+    float u, v;
+    uint32_t prim, bf, obj;
+};
+
+/* The tail of the accept branches of World::cast (main.rs:235-252, 304-313),
+ * evaluated once for the winning primitive instead of on every improvement. */
+__device__ __forceinline__ HitGeom finish_hit(const KernelScene &sc, const Ray &ray, const CastResult &r, bool want_sphere_uv_always) {
+    HitGeom h;
+    h.prim = (uint32_t)r.prim;
+    h.bf = r.bf;
+    h.pos = ray.o + ray.d * r.t;
+    if ((uint32_t)r.prim < sc.n_triangles) {
+        const DevTri &T = sc.tris[r.prim];
+        const DevTriAttr &A = sc.attrs[r.prim];
+        h.obj = T.obj;
+        const V3 bary = v3(r.a0, r.a1, r.a2) / T.area;
+        /* Matrix3::from_cols(n0,n1,n2) * bary: rows dotted with bary */
+        const V3 tmp = v3(dot(v3(A.n0[0], A.n1[0], A.n2[0]), bary),
+                          dot(v3(A.n0[1], A.n1[1], A.n2[1]), bary),
+                          dot(v3(A.n0[2], A.n1[2], A.n2[2]), bary));
+        h.normal = r.bf ? -tmp : tmp;
+        h.u = (A.uv0x * bary.x + A.uv1x * bary.y) + A.uv2x * bary.z;
+        h.v = (A.uv0y * bary.x + A.uv1y * bary.y) + A.uv2y * bary.z;
+    } else {
+        const DevSphere &S = sc.spheres[(uint32_t)r.prim - sc.n_triangles];
+        h.obj = S.obj;
+        const V3 tmp = normalize(h.pos - v3(S.c[0], S.c[1], S.c[2]));
+        h.normal = r.bf ? -tmp : tmp;
+        h.u = 0.0f;
+        h.v = 0.0f;
+        /* uv (main.rs:310-313) costs an acos and an atan2 and is only read by
+         * generative materials: evaluate it only for those (pure, so identical) */
+        if (want_sphere_uv_always || material_reads_uv(sc.materials[h.obj])) {
+            h.u = rtdm::acosf(h.normal.y) / RT_F_PI;
+            h.v = rtdm::atan2f(h.normal.z, h.normal.x) / (RT_F_PI * 2.0f) + 0.5f;
+        }
+    }
+    return h;
+}
+
+/* ---- the per-lane state machine ---------------------------------------------- */
+
+enum : uint32_t {
+    PH_DONE = 0u,
+    PH_NODE = 1u,        /* the pending cast is ray_trace's own cast          (main.rs:473) */
+    PH_SHADOW = 2u,      /* ... a shadow ray of get_shade's light loop        (main.rs:435) */
+    PH_REFR_INSIDE = 3u, /* ... get_refract's first inside cast               (main.rs:371) */
+    PH_REFR_BOUNCE = 4u  /* ... a total-internal-reflection bounce            (main.rs:381) */
+};
+
+/* One frame per ray_trace activation that has at least one child. */
+struct Frame {
+    V3 acc;            /* shade*sc, then (shade*sc + reflection*rc) */
+    float rc, fc;      /* reflection_contribution, refraction_contribution */
+    float decay;       /* opaque_decay.powf(travel_distance) */
+    float child_contribution; /* contribution of the refraction child */
+    V3 esc_o, esc_d;   /* escape ray (main.rs:393-401), valid when has_escape */
+    uint32_t esc_excl;
+    uint32_t flags;    /* bit0: reflection child running (else refraction child); bit1: has_escape */
+};
+
+template <int MAXD, bool USE_LDS>
+__global__ __launch_bounds__(RT_BLOCK_THREADS) void whitted_kernel(const KernelScene sc, const KernelFrame fr,
+                                                                     float *__restrict__ out,
+                                                                     unsigned long long *__restrict__ ray_count) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
+    const DevTri *lds_tris = nullptr;
+    if (USE_LDS) {
+        /* stage the triangle records once per workgroup: coalesced 16-byte loads, then broadcast reads */
+        const uint32_t n16 = sc.n_triangles * (uint32_t)(sizeof(DevTri) / 16);
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.tris);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        lds_tris = reinterpret_cast<const DevTri *>(lds_raw);
+    }
+
+    /* pixel assignment: wave w of the grid owns tile w, an 8x8 block of the (cols x rows) tile image */
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t tiles_x = (fr.cols + 7u) >> 3;
+    const uint32_t tile_y = wave / tiles_x, tile_x = wave - tile_y * tiles_x;
+    const uint32_t col = (tile_x << 3) + (lane & 7u);
+    const uint32_t row = (tile_y << 3) + (lane >> 3);
+    const bool in_image = col < fr.cols && row < fr.rows;
+
+    uint32_t phase = PH_DONE;
+    Ray req;
+    req.o = v3(0.0f, 0.0f, 0.0f);
+    req.d = v3(0.0f, 0.0f, 1.0f);
+    req.mode = FACE_FRONT;
+    req.excl = 0u;
+    uint32_t casts = 0u;
+
+    /* node context */
+    HitGeom nh;
+    nh.pos = nh.normal = v3(0.0f, 0.0f, 0.0f);
+    nh.u = nh.v = 0.0f;
+    nh.prim = nh.bf = nh.obj = 0u;
+    V3 n_in_dir = v3(0.0f, 0.0f, 0.0f); /* hit.ray.direction of the node hit */
+    uint32_t n_in_mode = FACE_FRONT;    /* hit.ray.face_direction */
+    float contribution = 1.0f;
+    int32_t sp = 0;                     /* depth = max_depth - sp */
+    /* shading context */
+    V3 sum = v3(0.0f, 0.0f, 0.0f), adj_n = v3(0.0f, 0.0f, 0.0f), l_color = v3(0.0f, 0.0f, 0.0f);
+    uint32_t light_i = 0u;
+    /* refraction context */
+    float travel = 0.0f;
+    int32_t retry = 0;
+    V3 node_acc = v3(0.0f, 0.0f, 0.0f); /* shade * shade_contribution of the current node */
+    V3 pixel = v3(0.0f, 0.0f, 0.0f);
+
+    Frame stack[MAXD];
+
+    if (in_image) {
+        /* main.rs:1093-1096 + Camera::shoot (main.rs:84-99) with the per-frame basis hoisted to the host */
+        const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+        const float clip_y = (fr.half_height - (float)y) / fr.height_f;
+        const float clip_x = ((float)x - fr.half_width) / fr.height_f;
+        const V3 cx = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
+        const V3 cy = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
+        const V3 ct = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
+        req.o = v3(fr.cam_origin[0], fr.cam_origin[1], fr.cam_origin[2]);
+        req.d = normalize(clip_x * cx + clip_y * cy + ct);
+        req.mode = FACE_FRONT;
+        req.excl = 0u;
+        /* ray_trace entry check (main.rs:469): contribution 1.0 >= THRESHOLD always holds at the root */
+        phase = PH_NODE;
+    }
+
+    const float THRESHOLD = 0.001f; /* main.rs:467 */
+
+    while (__builtin_amdgcn_ballot_w64(phase != PH_DONE) != 0ull) {
+        CastResult cr;
+        cr.prim = -1;
+        cr.t = 0.0f;
+        cr.bf = 0u;
+        cr.a0 = cr.a1 = cr.a2 = 0.0f;
+        if (phase != PH_DONE) {
+            cr = cast<USE_LDS>(sc, lds_tris, req);
+            casts += 1u;
+        }
+
+        /* ---- advance this lane until it needs another cast or finishes ---- */
+        if (phase != PH_DONE) {
+            /* `value` carries a finished subtree result up the frame stack */
+            V3 value = v3(0.0f, 0.0f, 0.0f);
+            enum { GO_NONE, GO_NEXT_LIGHT, GO_AFTER_SHADE, GO_TRY_EXIT, GO_CHILDREN, GO_RETURN } go = GO_NONE;
+            bool has_escape = false;
+            V3 esc_o = v3(0.0f, 0.0f, 0.0f), esc_d = esc_o;
+            uint32_t esc_excl = 0u;
+            float decay = 0.0f;
+            /* inside hit of get_refract, live only within this advance step */
+            HitGeom ih = nh;
+            V3 i_in_dir = req.d;
+            uint32_t i_in_mode = req.mode;
+
+            if (phase == PH_NODE) {
+                if (cr.prim < 0) {
+                    value = v3(0.0f, 0.0f, 0.0f); /* main.rs:475 */
+                    go = GO_RETURN;
+                } else {
+                    nh = finish_hit(sc, req, cr, false);
+                    n_in_dir = req.d;
+                    n_in_mode = req.mode;
+                    const rt_material &rm = sc.materials[nh.obj];
+                    const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                    if (contribution * shade_contribution >= THRESHOLD) { /* main.rs:480-483 */
+                        const Mat m = material_approx(rm, nh.u, nh.v);
+                        adj_n = adjust_normal(m.normal, nh.normal); /* main.rs:410 */
+                        sum = v3(0.0f, 0.0f, 0.0f);
+                        light_i = 0u;
+                        go = GO_NEXT_LIGHT;
+                    } else {
+                        sum = v3(0.0f, 0.0f, 0.0f);
+                        go = GO_AFTER_SHADE;
+                    }
+                }
+            } else if (phase == PH_SHADOW) {
+                /* main.rs:435-448 */
+                const rt_light &L = sc.lights[light_i];
+                bool lit = true;
+                if (cr.prim >= 0) {
+                    const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
+                    if (has_origin) {
+                        const V3 occ = req.o + req.d * cr.t;
+                        const float occlusion_distance = distance(nh.pos, occ);
+                        const float light_distance = distance(nh.pos, v3(L.origin[0], L.origin[1], L.origin[2]));
+                        if (occlusion_distance < light_distance) lit = false;
+                    } else {
+                        lit = false;
+                    }
+                }
+                if (lit) { /* main.rs:450-461 */
+                    const rt_material &rm = sc.materials[nh.obj];
+                    const Mat m = material_approx(rm, nh.u, nh.v);
+                    const V3 light_direction = req.d; /* = -light.direction */
+                    const V3 view_direction = -n_in_dir;
+                    const V3 diffuse = get_diffuse(m, adj_n, light_direction) * l_color;
+                    const V3 specular = get_specular(m, adj_n, view_direction, light_direction) * l_color;
+                    sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
+                }
+                light_i += 1u;
+                go = GO_NEXT_LIGHT;
+            } else { /* PH_REFR_INSIDE / PH_REFR_BOUNCE */
+                if (cr.prim < 0) {
+                    has_escape = false; /* Refraction::Infinite (main.rs:373, 383) */
+                    go = GO_CHILDREN;
+                } else {
+                    ih = finish_hit(sc, req, cr, false);
+                    i_in_dir = req.d;
+                    i_in_mode = req.mode;
+                    if (phase == PH_REFR_INSIDE) {
+                        travel = distance(ih.pos, nh.pos); /* main.rs:375 */
+                        retry = 0;
+                    } else {
+                        travel += distance(req.o, ih.pos); /* main.rs:385; req.o is the previous inside hit */
+                        retry += 1;
+                    }
+                    go = GO_TRY_EXIT;
+                }
+            }
+
+            /* small per-lane control loop; every path ends in a new cast request or PH_DONE */
+            for (;;) {
+                if (go == GO_NEXT_LIGHT) {
+                    /* the `for light in &self.lights` loop of get_shade up to the shadow cast (main.rs:413-433) */
+                    bool issued = false;
+                    while (light_i < sc.n_lights) {
+                        DirLight dl;
+                        if (approximate_into_directional(sc.lights[light_i], nh.pos, &dl)) {
+                            const float cosine = -dot(dl.direction, adj_n);
+                            if (!(cosine <= 0.0f)) {
+                                req.o = nh.pos;
+                                req.d = -dl.direction;
+                                req.mode = FACE_BACK;
+                                req.excl = pack_excl(nh.prim, FACE_BACK);
+                                l_color = dl.color;
+                                phase = PH_SHADOW;
+                                issued = true;
+                                break;
+                            }
+                        }
+                        light_i += 1u;
+                    }
+                    if (issued) break;
+                    go = GO_AFTER_SHADE;
+                } else if (go == GO_AFTER_SHADE) {
+                    /* `sum` is get_shade's result, or black when the shade branch was skipped */
+                    const int32_t depth = fr.max_depth - sp;
+                    if (depth <= 0) { /* main.rs:488-490: unscaled shade */
+                        value = sum;
+                        go = GO_RETURN;
+                        continue;
+                    }
+                    const rt_material &rm = sc.materials[nh.obj];
+                    const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                    node_acc = sum * shade_contribution;
+                    const float refraction_contribution = rm.transparency;
+                    if (contribution * refraction_contribution > THRESHOLD) { /* main.rs:502-505, strict */
+                        /* get_refract (main.rs:343-405) */
+                        V3 refract_in;
+                        if (refract_dir(nh.normal, n_in_dir, rm.refraction_index, &refract_in)) {
+                            req.o = nh.pos;
+                            req.d = normalize(refract_in); /* second normalize, main.rs:362 */
+                            req.mode = FACE_BACK;
+                            req.excl = pack_excl(nh.prim, FACE_FRONT);
+                            phase = PH_REFR_INSIDE;
+                            break;
+                        }
+                        /* Trapped */
+                    }
+                    has_escape = false;
+                    go = GO_CHILDREN;
+                } else if (go == GO_TRY_EXIT) {
+                    const rt_material &rm = sc.materials[nh.obj];
+                    const float k = rm.refraction_index;
+                    V3 out_dir;
+                    const bool have_out = refract_dir(ih.normal, i_in_dir, 1.0f / k, &out_dir);
+                    if (!have_out && travel <= 100.0f && retry < 10) { /* main.rs:378 */
+                        /* get_reflect(&hit_inside), main.rs:328-341 */
+                        req.o = ih.pos;
+                        req.d = reflect_dir(ih.normal, i_in_dir);
+                        req.mode = i_in_mode;
+                        req.excl = pack_excl(ih.prim, ih.bf ? FACE_FRONT : FACE_BACK); /* invert(hit.face_direction) */
+                        phase = PH_REFR_BOUNCE;
+                        break;
+                    }
+                    if (have_out) { /* Escaped, main.rs:392-403 */
+                        has_escape = true;
+                        esc_o = ih.pos;
+                        esc_d = normalize(out_dir);
+                        esc_excl = pack_excl(ih.prim, FACE_BACK);
+                        decay = rtdm::powf(rm.opaque_decay, travel); /* main.rs:508 */
+                    } else {
+                        has_escape = false; /* Trapped */
+                    }
+                    go = GO_CHILDREN;
+                } else if (go == GO_CHILDREN) {
+                    const rt_material &rm = sc.materials[nh.obj];
+                    const float rc = rm.shiness * (1.0f - rm.transparency); /* main.rs:493 */
+                    const float fc = rm.transparency;                       /* main.rs:502 */
+                    const bool want_refl = contribution * rc >= THRESHOLD;  /* main.rs:494-495 */
+                    const V3 black = v3(0.0f, 0.0f, 0.0f);
+                    if (!want_refl && !has_escape) {
+                        value = node_acc + black * rc + black * fc; /* main.rs:516-518 with both children black */
+                        go = GO_RETURN;
+                        continue;
+                    }
+                    Frame f;
+                    f.rc = rc;
+                    f.fc = fc;
+                    f.decay = decay;
+                    f.child_contribution = contribution * fc;
+                    f.esc_o = esc_o;
+                    f.esc_d = esc_d;
+                    f.esc_excl = esc_excl;
+                    if (want_refl) {
+                        f.acc = node_acc;
+                        f.flags = 1u | (has_escape ? 2u : 0u);
+                        /* get_reflect(&hit), main.rs:328-341 */
+                        req.o = nh.pos;
+                        req.d = reflect_dir(nh.normal, n_in_dir);
+                        req.mode = n_in_mode;
+                        req.excl = pack_excl(nh.prim, nh.bf ? FACE_FRONT : FACE_BACK);
+                        contribution = contribution * rc;
+                    } else {
+                        f.acc = node_acc + black * rc;
+                        f.flags = 2u;
+                        req.o = esc_o;
+                        req.d = esc_d;
+                        req.mode = FACE_FRONT;
+                        req.excl = esc_excl;
+                        contribution = f.child_contribution;
+                    }
+                    stack[sp] = f;
+                    sp += 1;
+                    phase = PH_NODE;
+                    break;
+                } else { /* GO_RETURN: unwind finished activations */
+                    if (sp == 0) {
+                        pixel = value;
+                        phase = PH_DONE;
+                        break;
+                    }
+                    Frame &f = stack[sp - 1];
+                    if (f.flags & 1u) { /* the reflection child just returned */
+                        f.acc = f.acc + value * f.rc;
+                        if (f.flags & 2u) {
+                            f.flags = 2u;
+                            req.o = f.esc_o;
+                            req.d = f.esc_d;
+                            req.mode = FACE_FRONT;
+                            req.excl = f.esc_excl;
+                            contribution = f.child_contribution;
+                            phase = PH_NODE;
+                            break;
+                        }
+                        value = f.acc + v3(0.0f, 0.0f, 0.0f) * f.fc;
+                    } else { /* the refraction child returned: shade * decay, then * fc */
+                        value = f.acc + (value * f.decay) * f.fc;
+                    }
+                    sp -= 1;
+                    /* restore the parent's contribution is unnecessary: a parent only needs it
+                     * before its children start, and every start writes `contribution` afresh */
+                }
+            }
+        }
+    }
+
+    if (in_image) {
+        /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
+        float *px = out + ((size_t)row * fr.cols + col) * 3u;
+        px[0] = 0.0f + pixel.x;
+        px[1] = 0.0f + pixel.y;
+        px[2] = 0.0f + pixel.z;
+    }
+
+    if (ray_count != nullptr) {
+        uint32_t c = casts;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0u && c != 0u) atomicAdd(ray_count, (unsigned long long)c);
+    }
+}
+
+} /* namespace rt */
+
+/* ---- launchers ------------------------------------------------------------------ */
+
+namespace rt {
+
+template <int MAXD>
+static hipError_t launch_maxd(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                              hipStream_t stream, bool use_lds) {
+    const uint32_t tiles = ((fr.cols + 7u) >> 3) * ((fr.rows + 7u) >> 3);
+    const uint32_t waves_per_block = RT_BLOCK_THREADS / 64;
+    const uint32_t blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    if (blocks == 0) return hipSuccess;
+    if (use_lds) {
+        const size_t lds = (size_t)sc.n_triangles * sizeof(DevTri);
+        hipLaunchKernelGGL((whitted_kernel<MAXD, true>), dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, sc, fr, out, ray_count);
+    } else {
+        hipLaunchKernelGGL((whitted_kernel<MAXD, false>), dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, sc, fr, out, ray_count);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                          hipStream_t stream, int variant) {
+    const bool use_lds = (variant & RT_VARIANT_LDS) != 0 && (size_t)sc.n_triangles * sizeof(DevTri) <= RT_LDS_SCENE_LIMIT;
+    if (fr.max_depth <= 8) return launch_maxd<8>(sc, fr, out, ray_count, stream, use_lds);
+    return launch_maxd<RT_MAX_DEPTH>(sc, fr, out, ray_count, stream, use_lds);
+}
+
+} /* namespace rt */
+
+/* ---- diagnostics: rt_detmath on the device ----------------------------------------- */
+
+namespace rt {
+
+/* host + device so rt_math_eval_host runs the very same source */
+__host__ __device__ float math_eval_one(int op, float x, float y) {
+    switch (op) {
+        case RT_MATH_SIN: return rtdm::sinf(x);
+        case RT_MATH_COS: return rtdm::cosf(x);
+        case RT_MATH_TAN: return rtdm::tanf(x);
+        case RT_MATH_ACOS: return rtdm::acosf(x);
+        case RT_MATH_ATAN2: return rtdm::atan2f(x, y);
+        case RT_MATH_POW: return rtdm::powf(x, y);
+        case RT_MATH_F32_DIV: return x / y;
+        case RT_MATH_F32_SQRT: return rtdm::f_sqrt(x);
+        case RT_MATH_F64_SQRT_HI: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits(rtdm::d_sqrt((double)x * (double)y)) >> 32));
+        case RT_MATH_F64_SQRT_LO: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits(rtdm::d_sqrt((double)x * (double)y))));
+        case RT_MATH_F64_DIV_HI: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits((double)x / (double)y) >> 32));
+        case RT_MATH_F64_DIV_LO: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits((double)x / (double)y)));
+        case RT_MATH_ROUND: return rtdm::f_round(x);
+        default: return 0.0f;
+    }
+}
+
+__global__ void math_eval_kernel(int op, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = math_eval_one(op, x[i], y[i]);
+}
+
+hipError_t launch_math_eval(int op, const float *d_x, const float *d_y, float *d_out, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, op, d_x, d_y, d_out, n);
+    return hipGetLastError();
+}
+
+void math_eval_host(int op, const float *x, const float *y, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) out[i] = math_eval_one(op, x[i], y ? y[i] : 0.0f);
+}
+
+} /* namespace rt */

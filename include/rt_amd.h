@@ -1,0 +1,220 @@
+/*
+ * rt_amd.h — C ABI of the MI355X-native render path.
+ *
+ * This is the drop-in boundary for the per-pixel render loop of
+ * foriequal0/homework-18-graphics-raytracer.  The reference has no FFI: its
+ * render loop is two rayon closures inside main() (src/main.rs:1090-1104 for
+ * the Whitted pass, src/main.rs:1131-1156 for the distributed pass).  The seam
+ * is created exactly there: everything those closures read (World, Camera,
+ * width/height/depth literals) comes in as flat POD arrays, and everything they
+ * produce (one LinSrgb per pixel) goes out as row-major f32 RGB.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns
+ * RT_OK (0) or a negative rt_status and never unwinds or aborts the host
+ * (the reference's convention is panic!/unwrap — src/main.rs:767-775,785 —
+ * which cannot cross a C ABI).  rt_last_error() returns a thread-local message
+ * for the last failing call.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1, /* null pointer, empty frame, index out of range ... */
+    RT_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime failure at init */
+    RT_ERR_HIP = -3,              /* a HIP call failed; rt_last_error() has hipGetErrorString */
+    RT_ERR_OUT_OF_MEMORY = -4,
+    RT_ERR_UNSUPPORTED = -5       /* e.g. max_depth above RT_MAX_DEPTH */
+} rt_status;
+
+/* Largest max_depth accepted by the render entry points (reference uses 5,
+ * src/main.rs:1098,1139; the benchmark uses 8). */
+#define RT_MAX_DEPTH 32
+
+/* ---- scene model: flat mirrors of the reference's types ------------------- */
+
+/* geometric.rs:42-47  PositionNormalUV { position, normal, uv } */
+typedef struct rt_vertex {
+    float position[3];
+    float normal[3];
+    float uv[2];
+} rt_vertex;
+
+/* primitives.rs:26-29  Triangle<PositionNormalUV> { object_index, vertices } */
+typedef struct rt_triangle {
+    uint32_t object_index; /* usize narrowed to u32 */
+    rt_vertex vertices[3];
+} rt_triangle;
+
+/* primitives.rs:15-24  Sphere { object_index, geometry: { center, radius } } */
+typedef struct rt_sphere {
+    uint32_t object_index;
+    float center[3];
+    float radius;
+} rt_sphere;
+
+/* materials.rs:70-83 stores two Rust closures in GenerativeMaterial; closures
+ * cannot cross a C ABI, so the closure bodies that exist in the reference
+ * (src/main.rs:848-863 and 1019-1026) are enumerated. */
+typedef enum rt_diffuse_fn {
+    RT_DIFFUSE_CONST = 0,      /* ColorMaterial: diffuse_color                    (materials.rs:33-37) */
+    RT_DIFFUSE_STRIPE_V = 1,   /* ((uv.y * f) as i32 % 2 == 0) ? tex_a : tex_b    (main.rs:848-854)   */
+    RT_DIFFUSE_STRIPE_SUM = 2  /* (((uv.x + uv.y) * f) as i32 % 2 == 0) ? a : b   (main.rs:1019-1025) */
+} rt_diffuse_fn;
+
+typedef enum rt_normal_fn {
+    RT_NORMAL_CONST = 0,       /* ColorMaterial.normal / |uv| (0,0,1)             (main.rs:1026)      */
+    RT_NORMAL_WAVE_U = 1       /* a = uv.x*nf*2*PI; v=(sin a,0,cos a); v.z<=0 ? -v : v (main.rs:855-863) */
+} rt_normal_fn;
+
+/* materials.rs:21-31 ColorMaterial (14 f32) + the enumerated closure parameters */
+typedef struct rt_material {
+    uint32_t diffuse_fn;       /* rt_diffuse_fn */
+    uint32_t normal_fn;        /* rt_normal_fn  */
+    float normal[3];           /* tangent-space bump normal, (0,0,1) for flat */
+    float diffuse_color[3];
+    float shiness;
+    float specular_color[3];
+    float smoothness;
+    float transparency;
+    float refraction_index;
+    float opaque_decay;
+    float tex_color_a[3];      /* generative diffuse: colour when the cell index is even */
+    float tex_color_b[3];      /*                     colour otherwise                   */
+    float tex_frequency;       /* 20.0 (main.rs:849) / 10.0 (main.rs:1020) */
+    float normal_frequency;    /* 10.0 (main.rs:856) */
+} rt_material;
+
+/* lights.rs:6-30 */
+typedef enum rt_light_kind {
+    RT_LIGHT_DIRECTIONAL = 0,
+    RT_LIGHT_SPOT = 1,
+    RT_LIGHT_POINT = 2
+} rt_light_kind;
+
+typedef struct rt_light {
+    uint32_t kind;        /* rt_light_kind */
+    uint32_t has_origin;  /* Directional.origin is Option<Point3> (lights.rs:8); Spot/Point always 1 */
+    float origin[3];
+    float direction[3];   /* Directional, Spot */
+    float angle;          /* Spot: radians */
+    float softness;       /* Spot */
+    float color[3];
+} rt_light;
+
+/* src/main.rs:130-137 World { objects, triangles, spheres, lights }.
+ * Array ORDER is semantically significant: nearest-hit ties resolve to the
+ * later primitive (main.rs:229-233, 298-302) and lights are summed in order. */
+typedef struct rt_scene_desc {
+    const rt_triangle *triangles; uint32_t n_triangles;
+    const rt_sphere   *spheres;   uint32_t n_spheres;
+    const rt_material *materials; uint32_t n_materials; /* one per Object (primitives.rs:8-10) */
+    const rt_light    *lights;    uint32_t n_lights;
+} rt_scene_desc;
+
+/* src/main.rs:43-49 */
+typedef struct rt_camera {
+    float fovy;       /* radians */
+    float center[3];
+    float toward[3];
+    float up[3];
+    float near;
+} rt_camera;
+
+/* Frame + tile.  The reference renders the full frame (main.rs:1084-1089);
+ * the tile fields are what image-tile sharding over several GPUs needs.
+ * Rendered pixels: x in [x0,x1), y in {y0, y0+y_step, ...} < y1.
+ * Output is compact: out[((row * (x1-x0)) + (x - x0)) * 3 + c], row = (y-y0)/y_step.
+ * With x0=y0=0, x1=width, y1=height, y_step=1 that is the reference's
+ * row-major [y*width + x] (image.rs:35-47). */
+typedef struct rt_frame {
+    uint32_t width, height;
+    int32_t  max_depth;      /* TraceState.depth at the root (main.rs:1098) */
+    uint32_t x0, y0, x1, y1;
+    uint32_t y_step;         /* >= 1 */
+} rt_frame;
+
+typedef struct rt_scene rt_scene; /* opaque: device-resident, immutable after create */
+
+/* ---- entry points --------------------------------------------------------- */
+
+/* ABI version of the loaded library (== RT_ABI_VERSION it was built with). */
+int rt_abi_version(void);
+
+/* Thread-local message for the last failing call on this thread ("" if none). */
+const char *rt_last_error(void);
+
+/* Number of HIP devices visible, or a negative rt_status. */
+int rt_device_count(void);
+
+/* Select the HIP device used by subsequent calls on this thread. */
+int rt_set_device(int device);
+
+/* Number of rows / pixels a frame's tile covers (host arithmetic only). */
+uint32_t rt_frame_rows(const rt_frame *frame);
+uint64_t rt_frame_pixels(const rt_frame *frame);
+
+/* Upload a scene to the current device.  Replaces the construction of `World`
+ * (src/main.rs:811-1075) as seen by the render loop: the library precomputes
+ * the per-triangle face normal and plane constant (primitives.rs:36-47,
+ * main.rs:202-203; pure functions of the vertices, so bit-identical to the
+ * reference's per-ray recomputation) and owns the device copy until destroy. */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene);
+int rt_scene_destroy(rt_scene *scene);
+
+/* Whitted pass over one tile: replaces the par_iter closure at
+ * src/main.rs:1090-1104 (shoot -> ray_trace(depth, contribution 1.0)).
+ *   d_rgb        device pointer, rt_frame_pixels(frame)*3 floats, linear radiance
+ *                BEFORE post_process (what ray_trace returns, main.rs:1101-1102).
+ *   d_ray_count  device pointer to one u64 or NULL; the number of World::cast
+ *                evaluations performed is ADDED to it (the reference only counts
+ *                pixels, main.rs:1108).
+ *   hip_stream   hipStream_t (as void*), NULL = default stream.  The launch is
+ *                stream-ordered and asynchronous. */
+int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame,
+                      float *d_rgb, unsigned long long *d_ray_count, void *hip_stream);
+
+/* Same, with host buffers: allocates, launches, copies back and synchronises.
+ * *h_ray_count is overwritten with the cast count of this call (may be NULL). */
+int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame,
+                           float *h_rgb, unsigned long long *h_ray_count);
+
+/* ---- diagnostics ------------------------------------------------------------ */
+
+/* Kernel variant used by the render entry points of this process:
+ *   0  triangle records fetched with wave-uniform scalar loads (SGPR broadcast)
+ *   1  triangle records staged in LDS once per workgroup (LDS broadcast)
+ * Default 0, or the value of the RT_AMD_VARIANT environment variable at load. */
+int rt_set_variant(int variant);
+int rt_get_variant(void);
+
+/* The deterministic f32 math the path computes with (csrc/rt_detmath.h),
+ * evaluated element-wise on the host or on the device, so tests can prove the
+ * two return identical bits.  op is an rt_math_op; y is ignored by unary ops.
+ * The *_HI/_LO ops return the two 32-bit halves of a binary64 result
+ * reinterpreted as f32 bit patterns (for checking f64 sqrt/div rounding). */
+typedef enum rt_math_op {
+    RT_MATH_SIN = 0, RT_MATH_COS = 1, RT_MATH_TAN = 2, RT_MATH_ACOS = 3,
+    RT_MATH_ATAN2 = 4,   /* atan2(x, y): x is the ordinate */
+    RT_MATH_POW = 5,     /* pow(x, y) */
+    RT_MATH_F32_DIV = 6, RT_MATH_F32_SQRT = 7,
+    RT_MATH_F64_SQRT_HI = 8, RT_MATH_F64_SQRT_LO = 9,   /* sqrt((double)x * (double)y) */
+    RT_MATH_F64_DIV_HI = 10, RT_MATH_F64_DIV_LO = 11,   /* (double)x / (double)y */
+    RT_MATH_ROUND = 12
+} rt_math_op;
+int rt_math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
+int rt_math_eval_device(int op, const float *h_x, const float *h_y, float *h_out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */
