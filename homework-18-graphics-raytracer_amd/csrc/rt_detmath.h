@@ -54,7 +54,7 @@ RT_HD bool is_normal(float x) {
 RT_HD double d_abs(double x) { return f64_from_bits(f64_bits(x) & 0x7fffffffffffffffull); }
 
 /* IEEE square roots (sqrtss / sqrtsd on the host, correctly rounded expansions
- * on gfx950 — verified bit-for-bit by tests/test_detmath_gpu.py). */
+ * on gfx950 — verified bit-for-bit by tests/test_gpu_detmath.py). */
 RT_HD float  f_sqrt(float x) { return __builtin_sqrtf(x); }
 RT_HD double d_sqrt(double x) { return __builtin_sqrt(x); }
 
@@ -141,6 +141,7 @@ RT_HD double reduce_pio2(float xf, int32_t *q) {
 
 RT_HD float sinf(float x) {
     if (is_nan(x) || is_inf(x)) return quiet_nan();
+    if (x == 0.0f) return x; /* sin(+-0) = +-0 */
     int32_t q;
     const double r = reduce_pio2(x, &q);
     double v;
@@ -169,6 +170,7 @@ RT_HD float cosf(float x) {
 
 RT_HD float tanf(float x) {
     if (is_nan(x) || is_inf(x)) return quiet_nan();
+    if (x == 0.0f) return x; /* tan(+-0) = +-0 */
     int32_t q;
     const double r = reduce_pio2(x, &q);
     const double s = sin_kernel(r), c = cos_kernel(r);

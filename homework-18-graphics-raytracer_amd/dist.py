@@ -1,0 +1,70 @@
+"""Image-tile sharding over the GPUs of one node.
+
+Pixels are independent (the reference's par_iter over (y, x), src/main.rs:1090), the scene is a few KB
+and is replicated on every rank, so the path shards with NO data-path collective: rank r renders the
+interleaved row band {r, r+N, r+2N, ...} (the cost per pixel is spatially non-uniform — background
+pixels cost one cast, glass pixels dozens — and interleaving rows balances it).  The only exchange is
+assembling the framebuffer on rank 0: one gather of the f32 RGB bands (RCCL over xGMI on GPUs, gloo in
+the CPU tests), then a de-interleave.
+
+One process per GPU; `backend="nccl"` is RCCL on ROCm.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+from ._capi import Frame
+
+
+def shard_frame(width: int, height: int, max_depth: int, rank: int, world: int) -> Frame:
+    """The tile of `rank`: all columns, rows rank, rank+world, ... (an rt_frame with y0=rank, y_step=world)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    if world > height:
+        raise ValueError("more ranks than image rows")
+    return Frame.rows_of_rank(width, height, max_depth, rank, world)
+
+
+def band_rows(height: int, rank: int, world: int) -> int:
+    return (height - rank + world - 1) // world
+
+
+def gather_frame(band, height: int, rank: int, world: int, dst: int = 0, group=None, staging=None):
+    """Assemble the full (height, width, 3) image on `dst` from every rank's row band.
+
+    `band`: this rank's (band_rows, width, 3) float32 tensor (CPU for gloo, CUDA for RCCL).
+    Returns the full image on `dst`, None elsewhere.  `staging` (optional, dst only) is a reusable
+    (world, max_rows, width, 3) buffer so that steady-state frames allocate nothing.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return band
+    width = band.shape[1]
+    max_rows = band_rows(height, 0, world)
+    if band.shape[0] != max_rows:  # ragged last bands: pad to the common size for the collective
+        padded = band.new_zeros((max_rows, width, 3))
+        padded[: band.shape[0]] = band
+        band = padded
+    if rank == dst:
+        if staging is None:
+            staging = band.new_empty((world, max_rows, width, 3))
+        dist.gather(band, [staging[r] for r in range(world)], dst=dst, group=group)
+        # de-interleave: image row y = k*world + r  <-  staging[r, k]
+        full = staging.permute(1, 0, 2, 3).reshape(max_rows * world, width, 3)
+        return full[:height].contiguous() if max_rows * world != height else full.contiguous()
+    dist.gather(band, None, dst=dst, group=group)
+    return None
+
+
+def render_frame_sharded(render_band: Callable[[Frame], "object"], width: int, height: int, max_depth: int, rank: int,
+                         world: int, dst: int = 0, group=None, staging=None):
+    """Render this rank's band with `render_band(frame) -> tensor` and gather the frame on `dst`.
+
+    `render_band` is the HIP path in production (homework_18_graphics_raytracer_amd.render_whitted);
+    the CPU/gloo tests inject the oracle here, which is the only reason it is a parameter.
+    """
+    frame = shard_frame(width, height, max_depth, rank, world)
+    band = render_band(frame)
+    return gather_frame(band, height, rank, world, dst=dst, group=group, staging=staging)
