@@ -36,6 +36,17 @@ struct alignas(32) DevTri {
 };
 static_assert(sizeof(DevTri) == 128, "DevTri must be 128 bytes");
 
+/* The 22 floats the intersection loop reads per triangle, packed to 96 bytes so that one triangle is
+ * three s_load_dwordx8 (or x16 + x8) into 24 SGPRs; two of these fit the SGPR file, which is what
+ * lets the loop fetch triangle i+1 while it tests triangle i (rt_kernels.hip, cast_sgpr). */
+struct alignas(32) DevTriHot {
+    float n[3]; float d;
+    float v0[3]; float v1[3]; float v2[3];
+    float e0[3]; float e1[3]; float e2[3];
+    float pad[2];
+};
+static_assert(sizeof(DevTriHot) == 96, "DevTriHot must be 96 bytes");
+
 /* per-vertex attributes, only read for the winning primitive of a cast */
 struct alignas(16) DevTriAttr {
     float n0[3]; float uv0x;

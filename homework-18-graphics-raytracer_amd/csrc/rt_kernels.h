@@ -11,7 +11,17 @@
 #include "../../include/rt_amd.h"
 #include "rt_device_scene.h"
 
-#define RT_BLOCK_THREADS 256
+#ifndef RT_BLOCK_THREADS
+#define RT_BLOCK_THREADS 64 /* one wave per workgroup: a finished wave frees its slot at once (256-thread groups idled 40 % of the slots) */
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4 /* <= 128 VGPRs; measured best among 2..8 (profiles/README.md) */
+#endif
+#ifdef RT_MIN_WAVES
+#define RT_LAUNCH_BOUNDS __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) /* 2nd arg: waves per SIMD */
+#else
+#define RT_LAUNCH_BOUNDS __launch_bounds__(RT_BLOCK_THREADS)
+#endif
 #define RT_LDS_SCENE_LIMIT (96u * 1024u) /* triangle records staged in LDS up to this many bytes */
 
 /* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant) */
@@ -23,6 +33,7 @@ namespace rt {
 /* device pointers + counts, passed by value as kernel arguments (lands in SGPRs) */
 struct KernelScene {
     const DevTri *tris;
+    const DevTriHot *hot;
     const DevTriAttr *attrs;
     const DevSphere *spheres;
     const rt_material *materials;

@@ -136,6 +136,142 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
     return best;
 }
 
+/* ---- cast, software-pipelined form ------------------------------------------------
+ * Same arithmetic as cast<> above, restructured for the machine:
+ *   - the 22 floats of a triangle arrive as ONE bulk scalar fetch (DevTriHot, 96 B);
+ *   - triangle i+1 is fetched while triangle i is tested (two SGPR buffers A/B; the
+ *     sched_barriers pin "wait for this buffer -> issue the next fetch -> compute",
+ *     because scalar loads return out of order and any wait is a wait for all);
+ *   - the per-lane accept predicate is carried as a mask and applied with selects
+ *     instead of nested exec regions; two wave ballots skip the rest of a triangle
+ *     when no lane is still alive (after culling/exclusion, and after t <= 0).
+ * Lanes that are not alive still execute the arithmetic; their results are discarded.
+ */
+struct TriAccum {
+    float t;
+    int32_t prim;
+    uint32_t bf;
+    float a0, a1, a2;
+    bool have;
+};
+
+struct RayCtx {
+    V3 o, d;
+    bool cull_back, cull_front, ex_some;
+    uint32_t ex_prim, ex_face;
+};
+
+__device__ __forceinline__ void test_triangle(const DevTriHot &T, uint32_t i, const RayCtx &r, float nd, TriAccum &best) {
+    const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+    const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
+    bool alive = !(bf ? r.cull_back : r.cull_front); /* main.rs:185-188 */
+    {
+        const bool criteria = r.ex_face == FACE_FRONT ? !bf : (r.ex_face == FACE_BACK ? bf : true);
+        alive = alive && !(r.ex_some && r.ex_prim == i && criteria); /* main.rs:190-200 */
+    }
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    const float t = (T.d - dot(n, r.o)) / nd; /* main.rs:203-204 */
+    alive = alive && !(t <= 0.0f);               /* NaN passes, as in the reference */
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    const V3 p = r.o + r.d * t;
+    const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
+    const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
+    const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
+    alive = alive && !(a0 < 0.0f || a1 < 0.0f || a2 < 0.0f); /* NaN areas pass (main.rs:224) */
+    alive = alive && !(best.have && best.t < t);             /* ties: the later primitive wins */
+    best.have = best.have || alive;
+    best.t = alive ? t : best.t;
+    best.prim = alive ? (int32_t)i : best.prim;
+    best.bf = alive ? (bf ? 1u : 0u) : best.bf;
+    best.a0 = alive ? a0 : best.a0;
+    best.a1 = alive ? a1 : best.a1;
+    best.a2 = alive ? a2 : best.a2;
+}
+
+typedef const float __attribute__((address_space(4))) *ConstF;
+
+/* one triangle record = 24 consecutive dwords, fetched through the constant address space */
+__device__ __forceinline__ DevTriHot load_hot(ConstF base, uint32_t i) {
+    const ConstF p = base + (size_t)i * (sizeof(DevTriHot) / sizeof(float));
+    DevTriHot h;
+    float *f = reinterpret_cast<float *>(&h);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(DevTriHot) / sizeof(float)); ++k) f[k] = p[k];
+    return h;
+}
+
+__device__ __forceinline__ CastResult cast_pipelined(const KernelScene &sc, const Ray &ray) {
+    TriAccum best;
+    best.prim = -1;
+    best.t = 0.0f;
+    best.bf = 0u;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    best.have = false;
+    RayCtx r;
+    r.o = ray.o;
+    r.d = ray.d;
+    r.cull_back = ray.mode == FACE_FRONT;
+    r.cull_front = ray.mode == FACE_BACK;
+    r.ex_some = (ray.excl >> 31) != 0u;
+    r.ex_prim = ray.excl & 0x1fffffffu;
+    r.ex_face = (ray.excl >> 29) & 3u;
+
+    const uint32_t nt = sc.n_triangles;
+    /* constant address space (4): the scene is immutable for the lifetime of the launch, which is what
+     * lets the compiler keep these wave-uniform fetches on the scalar unit (s_load) next to the sched_barriers */
+    const ConstF hot = (ConstF)(uintptr_t)sc.hot;
+    if (nt != 0u) {
+        DevTriHot A = load_hot(hot, 0u);
+        for (uint32_t i = 0; i < nt; i += 2u) {
+            /* first use of A: forces the wait for A's fetch */
+            const float ndA = dot(v3(A.n[0], A.n[1], A.n[2]), r.d);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t ib = (i + 1u < nt) ? i + 1u : i;
+            DevTriHot B = load_hot(hot, ib); /* in flight while A is tested */
+            __builtin_amdgcn_sched_barrier(0);
+            test_triangle(A, i, r, ndA, best);
+            __builtin_amdgcn_sched_barrier(0);
+            const float ndB = dot(v3(B.n[0], B.n[1], B.n[2]), r.d);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t ia = (i + 2u < nt) ? i + 2u : i;
+            A = load_hot(hot, ia); /* in flight while B is tested */
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1u < nt) test_triangle(B, i + 1u, r, ndB, best);
+        }
+    }
+
+    const uint32_t ns = sc.n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
+        const DevSphere &S = sc.spheres[i];
+        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
+        const V3 disp = c - r.o;
+        const float lsd = magnitude(cross(disp, r.d));
+        bool alive = !(lsd > S.radius);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+        const float tc = dot(r.d, disp);
+        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
+        const bool both_back = tc < k;
+        const bool bf = ray.mode == FACE_BACK || (ray.mode == FACE_BOTH && both_back);
+        const float t = bf ? tc + k : tc - k;
+        alive = alive && !(t <= 0.0f);
+        {
+            const bool criteria = r.ex_face == FACE_FRONT ? !bf : (r.ex_face == FACE_BACK ? bf : true);
+            alive = alive && !(r.ex_some && r.ex_prim == nt + i && criteria);
+        }
+        alive = alive && !(best.have && best.t < t);
+        best.have = best.have || alive;
+        best.t = alive ? t : best.t;
+        best.prim = alive ? (int32_t)(nt + i) : best.prim;
+        best.bf = alive ? (bf ? 1u : 0u) : best.bf;
+    }
+    CastResult out;
+    out.t = best.t;
+    out.prim = best.prim;
+    out.bf = best.bf;
+    out.a0 = best.a0; out.a1 = best.a1; out.a2 = best.a2;
+    return out;
+}
+
 /* What the state machine keeps of a Hit (main.rs:139-147). */
 struct HitGeom {
     V3 pos, normal;
@@ -201,7 +337,7 @@ struct Frame {
 };
 
 template <int MAXD, bool USE_LDS>
-__global__ __launch_bounds__(RT_BLOCK_THREADS) void whitted_kernel(const KernelScene sc, const KernelFrame fr,
+__global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr,
                                                                      float *__restrict__ out,
                                                                      unsigned long long *__restrict__ ray_count) {
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
@@ -278,7 +414,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS) void whitted_kernel(const KernelS
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
         if (phase != PH_DONE) {
+#ifdef RT_CAST_PIPELINED /* experiment: compiler-generated SGPR double buffering; slower than the plain loop (profiles/README) */
+            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_pipelined(sc, req);
+#else
             cr = cast<USE_LDS>(sc, lds_tris, req);
+#endif
             casts += 1u;
         }
 

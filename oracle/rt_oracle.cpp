@@ -802,8 +802,8 @@ void orc_ray_trace(const rt_scene_desc *scene, const orc_ray *ray, int32_t depth
 
 /* The Whitted driver, main.rs:1087-1109, over an rt_frame tile.  n_threads <= 0
  * means hardware_concurrency (mirrors rayon's global pool). */
-void orc_render_whitted(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
-                        uint64_t *out_casts, int n_threads) {
+static void render_whitted_impl(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
+                                uint64_t *out_casts, int n_threads, uint32_t *per_pixel_casts) {
     const uint32_t step = frame->y_step ? frame->y_step : 1;
     const uint32_t rows = frame->y1 > frame->y0 ? (frame->y1 - frame->y0 + step - 1) / step : 0;
     const uint32_t cols = frame->x1 > frame->x0 ? frame->x1 - frame->x0 : 0;
@@ -822,7 +822,9 @@ void orc_render_whitted(const rt_scene_desc *scene, const rt_camera *camera, con
                 float cx, cy;
                 clip_of(frame->width, frame->height, x, y, &cx, &cy);
                 Ray ray = shoot(*camera, cx, cy);
+                const uint64_t before = w.casts;
                 Rgb photon = ray_trace(w, frame->max_depth, 1.0f, ray);
+                if (per_pixel_casts) per_pixel_casts[(size_t)r * cols + c] = (uint32_t)(w.casts - before);
                 float *px = out_rgb + ((size_t)r * cols + c) * 3;
                 /* img[at] = img[at] + photon into a zeroed image (main.rs:1107) */
                 px[0] = 0.0f + photon.r;
@@ -837,6 +839,17 @@ void orc_render_whitted(const rt_scene_desc *scene, const rt_camera *camera, con
     worker();
     for (auto &t : pool) t.join();
     if (out_casts) *out_casts = total_casts.load();
+}
+
+void orc_render_whitted(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
+                        uint64_t *out_casts, int n_threads) {
+    render_whitted_impl(scene, camera, frame, out_rgb, out_casts, n_threads, nullptr);
+}
+
+/* same, also reporting the number of casts each pixel took (workload analysis) */
+void orc_render_whitted_counts(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
+                               uint32_t *per_pixel_casts, int n_threads) {
+    render_whitted_impl(scene, camera, frame, out_rgb, nullptr, n_threads, per_pixel_casts);
 }
 
 /* main.rs:748-762.  luma_mode 0: palette matrix-derived row; 1: literal

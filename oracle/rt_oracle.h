@@ -61,6 +61,8 @@ void orc_ray_trace(const rt_scene_desc *scene, const orc_ray *ray, int32_t depth
                    uint64_t *casts);
 void orc_render_whitted(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
                         uint64_t *out_casts, int n_threads);
+void orc_render_whitted_counts(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float *out_rgb,
+                               uint32_t *per_pixel_casts, int n_threads);
 float orc_post_process(float *rgb, size_t n_pixels, int luma_mode);
 void orc_luma_row(int luma_mode, float *row3);
 void orc_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out);

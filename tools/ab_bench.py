@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants in ONE process (cdna_hip_programming.md §5.4 rule 24).
+
+    python tools/ab_bench.py --tags base,wg64 [--rounds 7] [--frames 5] [--width 1920 --height 1080 --depth 8]
+
+Each tag is homework-18-graphics-raytracer_amd/variants/librt_amd_<tag>.so (make -C csrc variant TAG=.. EXTRA=..);
+"main" is the in-tree librt_amd.so.  Every variant's frame is checked bit-for-bit against the first one.
+"""
+import argparse
+import ctypes as C
+import statistics
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402  (first: one HIP runtime per process)
+
+import homework_18_graphics_raytracer_amd as rt  # noqa: E402
+from homework_18_graphics_raytracer_amd import _capi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tags", required=True)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--frames", type=int, default=5)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--variant", type=int, default=0)
+args = ap.parse_args()
+
+world = rt.reference_world()
+cam = rt.reference_camera()
+desc = world.desc()
+frame = rt.Frame.full(args.width, args.height, args.depth)
+libs = {}
+for tag in args.tags.split(","):
+    path = _capi.PKG_DIR / ("librt_amd.so" if tag == "main" else f"variants/librt_amd_{tag}.so")
+    lib = C.CDLL(str(path))
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_scene_create.argtypes = [C.POINTER(_capi.SceneDesc), C.POINTER(C.c_void_p)]
+    lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(_capi.Camera), C.POINTER(_capi.Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rt_set_variant(args.variant)
+    h = C.c_void_p()
+    assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0, lib.rt_last_error()
+    libs[tag] = (lib, h)
+
+out = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def run(tag, n):
+    lib, h = libs[tag]
+    for _ in range(n):
+        rc = lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(stream))
+        assert rc == 0, lib.rt_last_error()
+
+
+ref = None
+casts = None
+for tag in libs:
+    cnt.zero_()
+    run(tag, 2)
+    torch.cuda.synchronize()
+    img = out.clone()
+    c = int(cnt.item()) // 2
+    if ref is None:
+        ref, casts = img, c
+    else:
+        same = torch.equal(img.view(torch.int32), ref.view(torch.int32))
+        print(f"# {tag}: bit-identical to {next(iter(libs))}: {same}; casts {c} vs {casts}")
+times = {t: [] for t in libs}
+for r in range(args.rounds):
+    for tag in libs:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(tag, args.frames)
+        e1.record()
+        torch.cuda.synchronize()
+        times[tag].append(e0.elapsed_time(e1) / args.frames)
+for tag, ts in times.items():
+    med, mn = statistics.median(ts), min(ts)
+    print(f"{tag:16s} median {med:8.4f} ms  min {mn:8.4f} ms   {casts / med / 1e3:9.1f} Mrays/s (median)  {casts / mn / 1e3:9.1f} (best)")
