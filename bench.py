@@ -40,7 +40,7 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--variant", type=int, default=None, help="kernel variant (0 SGPR broadcast, 1 LDS broadcast)")
+    p.add_argument("--variant", type=int, default=None, help="kernel variant: bit 0 = LDS broadcast (else SGPR); bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
     return p.parse_args()
@@ -201,7 +201,7 @@ def main() -> int:
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
                 "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0" if distributed else ""),
-                "kernel_variant": "lds" if variant == 1 else "sgpr",
+                "kernel_variant": ("lds" if variant & 1 else "sgpr") + "+" + {0: "cost-sorted-tiles", 2: "static-tiles", 4: "persistent-lanes", 6: "two-phase"}[variant & 6],
             },
             "casts_per_frame": casts_per_frame,
             "casts_per_pixel": round(casts_per_frame / (W * H), 3),

@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,11 +28,31 @@ namespace rt {
 void math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
 }
 
+/* Per-(scene, stream) scratch: the two queue counters and the continuation buffer of the two-phase
+ * scheme.  Launches on one stream are ordered, so they can share it; other streams get their own.
+ * Grow-only; allocated on the first call that needs it (not inside a graph capture). */
+struct Workspace {
+    uint32_t *d_counters = nullptr; /* [0] chunk counter, [1] continuation count */
+    uint32_t *d_cont = nullptr;
+    size_t cont_bytes = 0;
+    uint32_t *d_tiles = nullptr; /* tile_cost[n] then tile_order[n] */
+    size_t tiles_n = 0;
+};
+
 struct rt_scene {
     int device;
     void *d_blob; /* one allocation holding every array */
     rt::KernelScene ks;
+    uint32_t resident_waves; /* CUs * 4 SIMDs * RT_MIN_WAVES: the persistent grid */
+    std::mutex ws_mutex;
+    std::map<hipStream_t, Workspace> workspaces;
 };
+
+static int g_evict_threshold = -1, g_evict_min_iter = -1;
+#ifdef RT_DIAG_TIMELINE
+static unsigned long long *g_diag_timeline = nullptr;
+extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
+#endif
 
 static thread_local std::string g_error;
 static int g_variant = -1;
@@ -55,7 +77,7 @@ static int current_variant() {
     if (g_variant < 0) {
         const char *v = getenv("RT_AMD_VARIANT");
         g_variant = (v && *v) ? atoi(v) : RT_VARIANT_SGPR;
-        if (g_variant < 0 || g_variant > 1) g_variant = RT_VARIANT_SGPR;
+        if (g_variant < 0 || g_variant > RT_VARIANT_MAX) g_variant = RT_VARIANT_SGPR;
     }
     return g_variant;
 }
@@ -84,11 +106,18 @@ int rt_set_device(int device) {
 }
 
 int rt_set_variant(int variant) {
-    if (variant < 0 || variant > 1) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: variant must be 0 or 1");
+    if (variant < 0 || variant > RT_VARIANT_MAX) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: variant out of range");
     g_variant = variant;
     return RT_OK;
 }
 int rt_get_variant(void) { return current_variant(); }
+
+int rt_set_eviction(int threshold, int min_iterations) {
+    if (threshold < 0 || threshold > 63 || min_iterations < 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_eviction: threshold 0..63, min_iterations >= 0");
+    g_evict_threshold = threshold;
+    g_evict_min_iter = min_iterations;
+    return RT_OK;
+}
 
 uint32_t rt_frame_rows(const rt_frame *f) {
     if (!frame_ok(f)) return 0;
@@ -207,6 +236,10 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.n_spheres = desc->n_spheres;
     sc->ks.n_materials = desc->n_materials;
     sc->ks.n_lights = desc->n_lights;
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
+    if (e != hipSuccess || cus <= 0) cus = 256;
+    sc->resident_waves = (uint32_t)cus * 4u * (uint32_t)RT_MIN_WAVES;
     *out_scene = sc;
     return RT_OK;
 }
@@ -214,6 +247,11 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
 int rt_scene_destroy(rt_scene *scene) {
     if (!scene) return RT_OK;
     hipError_t e = hipSuccess;
+    for (auto &kv : scene->workspaces) {
+        if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
+        if (kv.second.d_cont) (void)hipFree(kv.second.d_cont);
+        if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+    }
     if (scene->d_blob) e = hipFree(scene->d_blob);
     delete scene;
     if (e != hipSuccess) return fail_hip("rt_scene_destroy: hipFree", e);
@@ -255,7 +293,60 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     rt::KernelFrame kf;
     int rc = make_kernel_frame(camera, frame, &kf);
     if (rc != RT_OK) return rc;
-    hipError_t e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, static_cast<hipStream_t>(hip_stream), current_variant());
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int variant = current_variant();
+    if (g_evict_threshold < 0) {
+        const char *v = getenv("RT_AMD_EVICT_THRESHOLD");
+        g_evict_threshold = (v && *v) ? atoi(v) : 16;
+        if (g_evict_threshold < 0 || g_evict_threshold > 63) g_evict_threshold = 16;
+        const char *m = getenv("RT_AMD_EVICT_MIN_ITER");
+        g_evict_min_iter = (m && *m) ? atoi(m) : 4;
+    }
+    rt::KernelQueues qs;
+    memset(&qs, 0, sizeof qs);
+    qs.evict_threshold = (uint32_t)g_evict_threshold;
+    qs.evict_min_iterations = (uint32_t)g_evict_min_iter;
+    {
+        rt_scene *mut = const_cast<rt_scene *>(scene); /* workspaces are the only mutable part of a scene */
+        std::lock_guard<std::mutex> lock(mut->ws_mutex);
+        Workspace &ws = mut->workspaces[stream];
+        if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
+        if ((variant & RT_VARIANT_SCHEME_MASK) == RT_VARIANT_TWO_PHASE) {
+            /* a wave evicts at most evict_threshold lanes, once */
+            const uint64_t chunks = ((uint64_t)kf.cols * kf.rows + 63u) / 64u;
+            const uint64_t capacity = chunks * (qs.evict_threshold ? qs.evict_threshold : 1u);
+            const size_t need = (size_t)capacity * rt::cont_record_dwords(kf.max_depth) * sizeof(uint32_t);
+            if (need > ws.cont_bytes) {
+                if (ws.d_cont) (void)hipFree(ws.d_cont);
+                ws.d_cont = nullptr;
+                ws.cont_bytes = 0;
+                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_cont), need));
+                ws.cont_bytes = need;
+            }
+            qs.cont_buf = ws.d_cont;
+            qs.cont_capacity = (uint32_t)(capacity > 0xffffffffull ? 0xffffffffull : capacity);
+        }
+        if ((variant & RT_VARIANT_SCHEME_MASK) == RT_VARIANT_SORTED) {
+            const size_t chunks = (size_t)(((uint64_t)kf.cols * kf.rows + 63u) / 64u);
+            const size_t padded = (chunks + 63u) & ~(size_t)63u; /* the probe writes one cost per lane */
+            if (padded > ws.tiles_n) {
+                if (ws.d_tiles) (void)hipFree(ws.d_tiles);
+                ws.d_tiles = nullptr;
+                ws.tiles_n = 0;
+                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_tiles), 2 * padded * sizeof(uint32_t)));
+                ws.tiles_n = padded;
+            }
+            qs.tile_cost = ws.d_tiles;
+            qs.tile_order = ws.d_tiles + ws.tiles_n;
+        }
+        qs.work_queue = ws.d_counters;
+        qs.cont_count = ws.d_counters + 1;
+#ifdef RT_DIAG_TIMELINE
+        qs.timeline = g_diag_timeline;
+#endif
+    }
+    hipError_t e = hipMemsetAsync(qs.work_queue, 0, 2 * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
     return RT_OK;
 }

@@ -26,7 +26,13 @@
 
 /* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant) */
 #define RT_VARIANT_SGPR 0 /* triangle records fetched with wave-uniform scalar loads */
-#define RT_VARIANT_LDS 1  /* triangle records staged in LDS once per workgroup     */
+#define RT_VARIANT_LDS 1          /* bit 0: triangle records staged in LDS once per workgroup */
+#define RT_VARIANT_SCHEME_MASK 6  /* bits 1-2: how pixels reach lanes */
+#define RT_VARIANT_SORTED 0       /*   one 8x8 tile per wave, tiles dispatched most-expensive-first (cost probe + sort; default) */
+#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (the round-1 v1 scheme) */
+#define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
+#define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
+#define RT_VARIANT_MAX 7
 
 namespace rt {
 
@@ -45,6 +51,7 @@ struct KernelScene {
  * hoisted to the host: it is the same for every ray */
 struct KernelFrame {
     uint32_t cols, rows;     /* tile size in pixels */
+    uint32_t n_chunks;       /* ceil(cols*rows / 64), filled by the launcher */
     uint32_t x0, y0, y_step; /* tile origin and row stride in the image */
     int32_t max_depth;
     float half_height;       /* height as f32 / 2.0   (main.rs:1094) */
@@ -56,8 +63,23 @@ struct KernelFrame {
     float cam_toward[3];     /* normalize(toward) */
 };
 
+/* device-side queues of one launch */
+struct KernelQueues {
+    uint32_t *work_queue;          /* chunk counter (zeroed per launch) */
+    uint32_t *cont_count;          /* number of evicted lane states (zeroed per launch) */
+    uint32_t *cont_buf;            /* cont_capacity records of cont_record_dwords(max_depth) dwords */
+    uint32_t cont_capacity;
+    uint32_t evict_threshold;      /* phase 1 leaves when at most this many lanes are still active ... */
+    uint32_t evict_min_iterations; /* ... and it has done at least this many casts */
+    uint32_t *tile_cost;           /* n_chunks probe costs (RT_VARIANT_SORTED) */
+    uint32_t *tile_order;          /* n_chunks chunk ids, most expensive first */
+    unsigned long long *timeline;  /* diagnostic builds (RT_DIAG_TIMELINE): 4 u64 per wave, else unused */
+};
+
+uint32_t cont_record_dwords(int32_t max_depth);
+
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
-                          hipStream_t stream, int variant);
+                          const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
 
 /* diagnostics: evaluate rt_detmath on the device (op codes = rt_math_op) */
 hipError_t launch_math_eval(int op, const float *d_x, const float *d_y, float *d_out, size_t n, hipStream_t stream);

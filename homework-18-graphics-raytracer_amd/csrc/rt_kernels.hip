@@ -272,6 +272,114 @@ __device__ __forceinline__ CastResult cast_pipelined(const KernelScene &sc, cons
     return out;
 }
 
+/* cast, bulk-fetch form: the control flow of cast<> (nested early-outs), but each triangle's 22 floats
+ * arrive as one 96-byte scalar fetch through the constant address space, RT_CAST_UNROLL triangles per
+ * wait, instead of three dependent fetches per triangle. */
+#ifndef RT_CAST_UNROLL
+#define RT_CAST_UNROLL 2
+#endif
+__device__ __forceinline__ CastResult cast_bulk(const KernelScene &sc, const Ray &ray) {
+    CastResult best;
+    best.prim = -1;
+    best.t = 0.0f;
+    best.bf = 0u;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    bool have = false;
+    const bool cull_back = ray.mode == FACE_FRONT;
+    const bool cull_front = ray.mode == FACE_BACK;
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+    const uint32_t nt = sc.n_triangles;
+    const ConstF hot = (ConstF)(uintptr_t)sc.hot;
+    for (uint32_t base = 0; base < nt; base += RT_CAST_UNROLL) {
+        DevTriHot Ts[RT_CAST_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RT_CAST_UNROLL; ++u) Ts[u] = load_hot(hot, (base + u < nt) ? base + u : nt - 1u);
+#pragma unroll
+        for (int u = 0; u < RT_CAST_UNROLL; ++u) {
+            const uint32_t i = base + (uint32_t)u;
+            if (i >= nt) break;
+            const DevTriHot &T = Ts[u];
+            const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+            const float nd = dot(n, ray.d);
+            const bool bf = nd > 0.0f;
+            if (bf ? cull_back : cull_front) continue;
+            if (ex_some && ex_prim == i) {
+                const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+                if (criteria) continue;
+            }
+            const float t = (T.d - dot(n, ray.o)) / nd;
+            if (t <= 0.0f) continue;
+            const V3 p = ray.o + ray.d * t;
+            const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
+            const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
+            const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
+            if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue;
+            if (have && best.t < t) continue;
+            have = true;
+            best.t = t;
+            best.prim = (int32_t)i;
+            best.bf = bf ? 1u : 0u;
+            best.a0 = a0; best.a1 = a1; best.a2 = a2;
+        }
+    }
+    const uint32_t ns = sc.n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
+        const DevSphere &S = sc.spheres[i];
+        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
+        const V3 disp = c - ray.o;
+        const float lsd = magnitude(cross(disp, ray.d));
+        if (lsd > S.radius) continue;
+        const float tc = dot(ray.d, disp);
+        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
+        float t;
+        bool bf;
+        if (ray.mode == FACE_FRONT) { t = tc - k; bf = false; }
+        else if (ray.mode == FACE_BACK) { t = tc + k; bf = true; }
+        else if (tc < k) { t = tc + k; bf = true; }
+        else { t = tc - k; bf = false; }
+        if (t <= 0.0f) continue;
+        if (ex_some && ex_prim == nt + i) {
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        if (have && best.t < t) continue;
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)(nt + i);
+        best.bf = bf ? 1u : 0u;
+    }
+    return best;
+}
+
+/* Out-of-line instance of the scalar-fetch cast.  Keeping the intersection loop in its own function gives it
+ * its own register allocation: the surrounding state machine (and whatever is added to it) can no longer push
+ * spills or extra live ranges into the loop that does 95 % of the work. */
+#ifdef RT_CAST_OUTLINED /* experiment: measured 1.5x slower — function arguments arrive in VGPRs, so the triangle fetches stop being scalar */
+__device__ __attribute__((noinline)) CastResult cast_outlined(const DevTri *tris, uint32_t n_triangles, const DevSphere *spheres,
+                                                              uint32_t n_spheres, float ox, float oy, float oz, float dx, float dy,
+                                                              float dz, uint32_t mode, uint32_t excl) {
+    KernelScene sc;
+    sc.tris = tris;
+    sc.attrs = nullptr;
+    sc.hot = nullptr;
+    sc.spheres = spheres;
+    sc.materials = nullptr;
+    sc.lights = nullptr;
+    sc.n_triangles = n_triangles;
+    sc.n_spheres = n_spheres;
+    sc.n_materials = 0u;
+    sc.n_lights = 0u;
+    Ray r;
+    r.o = v3(ox, oy, oz);
+    r.d = v3(dx, dy, dz);
+    r.mode = mode;
+    r.excl = excl;
+    return cast<false>(sc, nullptr, r);
+}
+#endif
+
 /* What the state machine keeps of a Hit (main.rs:139-147). */
 struct HitGeom {
     V3 pos, normal;
@@ -336,10 +444,85 @@ struct Frame {
     uint32_t flags;    /* bit0: reflection child running (else refraction child); bit1: has_escape */
 };
 
-template <int MAXD, bool USE_LDS>
-__global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr,
-                                                                     float *__restrict__ out,
-                                                                     unsigned long long *__restrict__ ray_count) {
+/* Serialise / restore a lane's state.  Macros because they touch two dozen of the kernel's locals. */
+#define CONT_F(i, x) rec[i] = __float_as_uint(x)
+#define STORE_CONT(rec)                                                                                     \
+    do {                                                                                                    \
+        rec[0] = phase; rec[1] = (uint32_t)sp; rec[2] = out_index; rec[3] = req.mode; rec[4] = req.excl;    \
+        rec[5] = nh.prim; rec[6] = nh.bf; rec[7] = nh.obj; rec[8] = n_in_mode; rec[9] = light_i;            \
+        rec[10] = (uint32_t)retry;                                                                          \
+        CONT_F(11, req.o.x); CONT_F(12, req.o.y); CONT_F(13, req.o.z);                                      \
+        CONT_F(14, req.d.x); CONT_F(15, req.d.y); CONT_F(16, req.d.z);                                      \
+        CONT_F(17, nh.pos.x); CONT_F(18, nh.pos.y); CONT_F(19, nh.pos.z);                                   \
+        CONT_F(20, nh.normal.x); CONT_F(21, nh.normal.y); CONT_F(22, nh.normal.z);                          \
+        CONT_F(23, nh.u); CONT_F(24, nh.v);                                                                 \
+        CONT_F(25, n_in_dir.x); CONT_F(26, n_in_dir.y); CONT_F(27, n_in_dir.z);                             \
+        CONT_F(28, contribution);                                                                           \
+        CONT_F(29, sum.x); CONT_F(30, sum.y); CONT_F(31, sum.z);                                            \
+        CONT_F(32, adj_n.x); CONT_F(33, adj_n.y); CONT_F(34, adj_n.z);                                      \
+        CONT_F(35, l_color.x); CONT_F(36, l_color.y); CONT_F(37, l_color.z);                                \
+        CONT_F(38, travel);                                                                                 \
+        CONT_F(39, node_acc.x); CONT_F(40, node_acc.y); CONT_F(41, node_acc.z);                             \
+        for (int32_t fi = 0; fi < sp; ++fi) {                                                               \
+            const Frame &f = stack[fi];                                                                     \
+            uint32_t *fr_ = rec + CONT_FIXED + FRAME_DWORDS * (uint32_t)fi;                                 \
+            fr_[0] = __float_as_uint(f.acc.x); fr_[1] = __float_as_uint(f.acc.y); fr_[2] = __float_as_uint(f.acc.z); \
+            fr_[3] = __float_as_uint(f.rc); fr_[4] = __float_as_uint(f.fc); fr_[5] = __float_as_uint(f.decay); \
+            fr_[6] = __float_as_uint(f.child_contribution);                                                 \
+            fr_[7] = __float_as_uint(f.esc_o.x); fr_[8] = __float_as_uint(f.esc_o.y); fr_[9] = __float_as_uint(f.esc_o.z); \
+            fr_[10] = __float_as_uint(f.esc_d.x); fr_[11] = __float_as_uint(f.esc_d.y); fr_[12] = __float_as_uint(f.esc_d.z); \
+            fr_[13] = f.esc_excl; fr_[14] = f.flags;                                                        \
+        }                                                                                                   \
+    } while (0)
+#define CONT_G(i) __uint_as_float(rec[i])
+#define LOAD_CONT(rec)                                                                                      \
+    do {                                                                                                    \
+        phase = rec[0]; sp = (int32_t)rec[1]; out_index = rec[2]; req.mode = rec[3]; req.excl = rec[4];     \
+        nh.prim = rec[5]; nh.bf = rec[6]; nh.obj = rec[7]; n_in_mode = rec[8]; light_i = rec[9];            \
+        retry = (int32_t)rec[10];                                                                           \
+        req.o = v3(CONT_G(11), CONT_G(12), CONT_G(13)); req.d = v3(CONT_G(14), CONT_G(15), CONT_G(16));     \
+        nh.pos = v3(CONT_G(17), CONT_G(18), CONT_G(19)); nh.normal = v3(CONT_G(20), CONT_G(21), CONT_G(22)); \
+        nh.u = CONT_G(23); nh.v = CONT_G(24);                                                               \
+        n_in_dir = v3(CONT_G(25), CONT_G(26), CONT_G(27)); contribution = CONT_G(28);                       \
+        sum = v3(CONT_G(29), CONT_G(30), CONT_G(31)); adj_n = v3(CONT_G(32), CONT_G(33), CONT_G(34));       \
+        l_color = v3(CONT_G(35), CONT_G(36), CONT_G(37)); travel = CONT_G(38);                              \
+        node_acc = v3(CONT_G(39), CONT_G(40), CONT_G(41));                                                  \
+        for (int32_t fi = 0; fi < sp; ++fi) {                                                               \
+            const uint32_t *fr_ = rec + CONT_FIXED + FRAME_DWORDS * (uint32_t)fi;                           \
+            Frame f;                                                                                        \
+            f.acc = v3(__uint_as_float(fr_[0]), __uint_as_float(fr_[1]), __uint_as_float(fr_[2]));          \
+            f.rc = __uint_as_float(fr_[3]); f.fc = __uint_as_float(fr_[4]); f.decay = __uint_as_float(fr_[5]); \
+            f.child_contribution = __uint_as_float(fr_[6]);                                                 \
+            f.esc_o = v3(__uint_as_float(fr_[7]), __uint_as_float(fr_[8]), __uint_as_float(fr_[9]));        \
+            f.esc_d = v3(__uint_as_float(fr_[10]), __uint_as_float(fr_[11]), __uint_as_float(fr_[12]));     \
+            f.esc_excl = fr_[13]; f.flags = fr_[14];                                                        \
+            stack[fi] = f;                                                                                  \
+        }                                                                                                   \
+    } while (0)
+
+#ifndef RT_PRIO_STEP1
+#define RT_PRIO_STEP1 9u
+#define RT_PRIO_STEP2 14u
+#define RT_PRIO_STEP3 20u
+#endif
+
+/* Work-source modes of the kernel (see "Work assignment" below). */
+enum : int {
+    MODE_STATIC = 0,     /* one 64-slot chunk per wave, run to completion                                   */
+    MODE_PERSISTENT = 1, /* lanes refill pixel by pixel from a global chunk counter                          */
+    MODE_PHASE1 = 2,     /* one chunk per wave; when few lanes are left their state is evicted to a queue     */
+    MODE_PHASE2 = 3,     /* lanes load evicted states (continuations) from that queue, refilling as they end  */
+    MODE_COST = 4        /* probe: lane k casts the primary ray of the middle pixel of chunk k and grades what it hit */
+};
+
+/* A continuation = everything a lane carries between two casts: CONT_FIXED dwords + its frame stack. */
+#define CONT_FIXED 48u
+#define FRAME_DWORDS 15u
+
+template <int MAXD, bool USE_LDS, int MODE>
+__global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr, float *__restrict__ out,
+                                                unsigned long long *__restrict__ ray_count, const KernelQueues qs) {
+    uint32_t *__restrict__ work_queue = qs.work_queue;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     const DevTri *lds_tris = nullptr;
     if (USE_LDS) {
@@ -352,14 +535,43 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         lds_tris = reinterpret_cast<const DevTri *>(lds_raw);
     }
 
-    /* pixel assignment: wave w of the grid owns tile w, an 8x8 block of the (cols x rows) tile image */
+    /* Work assignment.  The tile image (cols x rows) is enumerated as "slots": 8-row bands, column-major
+     * inside a band, so 64 consecutive slots are an 8x8 pixel block (8 x fewer rows in a ragged last band).
+     * A wave owns a local run of slots [q_next, q_end).  Lanes whose pixel is finished take the next slots
+     * of the run (ballot + prefix count, no atomics); when the run is empty the wave pulls the next
+     * 64-slot chunk from a global counter (PERSISTENT) — one atomic per 64 pixels — so every lane stays
+     * busy until the frame runs dry and no wave outlives the others by more than one pixel's work.
+     * Without PERSISTENT each wave gets exactly one chunk (the round-1 v1 scheme, kept for A/B). */
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t tiles_x = (fr.cols + 7u) >> 3;
-    const uint32_t tile_y = wave / tiles_x, tile_x = wave - tile_y * tiles_x;
-    const uint32_t col = (tile_x << 3) + (lane & 7u);
-    const uint32_t row = (tile_y << 3) + (lane >> 3);
-    const bool in_image = col < fr.cols && row < fr.rows;
+#ifdef RT_DIAG_TIMELINE /* diagnostic build only: wave start/end on the 100 MHz constant clock, iterations, HW id */
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t total_slots = fr.cols * fr.rows;
+    const uint32_t band_slots = fr.cols << 3;
+    uint32_t q_next = 0u, q_end = 0u;
+    bool exhausted = false;
+    if (MODE == MODE_STATIC || MODE == MODE_PHASE1) {
+        /* which chunk this wave renders: dispatch position `wave`, or — when a cost-sorted order exists —
+         * the wave-th most expensive chunk, so that the long tiles start first and the cheap ones fill the end */
+        uint32_t chunk = wave;
+        if (MODE == MODE_STATIC && qs.tile_order != nullptr && wave < fr.n_chunks) chunk = qs.tile_order[wave];
+        q_next = chunk * 64u < total_slots ? chunk * 64u : total_slots;
+        q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
+        exhausted = true;
+    }
+    if (MODE == MODE_COST) {
+        /* one probe pixel per lane: the middle slot of chunk (wave*64 + lane), handed out by the refill code
+         * below on its first trip (a pretend run of 64 slots that is consumed at once) */
+        q_next = 0u;
+        q_end = 64u;
+        exhausted = true;
+    }
+    /* MODE_PHASE2: slots are continuation records; their number was left in qs.cont_count by phase 1 */
+    const uint32_t n_cont = MODE == MODE_PHASE2 ? *qs.cont_count : 0u;
+    const uint32_t cont_stride = CONT_FIXED + FRAME_DWORDS * (uint32_t)MAXD;
+    uint32_t iteration = 0u;
+    uint32_t out_index = 0u; /* row * cols + col of the pixel this lane is working on */
 
     uint32_t phase = PH_DONE;
     Ray req;
@@ -385,29 +597,111 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
     float travel = 0.0f;
     int32_t retry = 0;
     V3 node_acc = v3(0.0f, 0.0f, 0.0f); /* shade * shade_contribution of the current node */
-    V3 pixel = v3(0.0f, 0.0f, 0.0f);
 
     Frame stack[MAXD];
 
-    if (in_image) {
-        /* main.rs:1093-1096 + Camera::shoot (main.rs:84-99) with the per-frame basis hoisted to the host */
-        const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
-        const float clip_y = (fr.half_height - (float)y) / fr.height_f;
-        const float clip_x = ((float)x - fr.half_width) / fr.height_f;
-        const V3 cx = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
-        const V3 cy = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
-        const V3 ct = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
-        req.o = v3(fr.cam_origin[0], fr.cam_origin[1], fr.cam_origin[2]);
-        req.d = normalize(clip_x * cx + clip_y * cy + ct);
-        req.mode = FACE_FRONT;
-        req.excl = 0u;
-        /* ray_trace entry check (main.rs:469): contribution 1.0 >= THRESHOLD always holds at the root */
-        phase = PH_NODE;
-    }
-
     const float THRESHOLD = 0.001f; /* main.rs:467 */
 
-    while (__builtin_amdgcn_ballot_w64(phase != PH_DONE) != 0ull) {
+    bool cost_started = false;
+    for (;;) {
+        /* ---- refill idle lanes ---- */
+        unsigned long long need = __builtin_amdgcn_ballot_w64(phase == PH_DONE);
+        if (MODE == MODE_COST) need = cost_started ? 0ull : need;
+        while (need != 0ull) {
+            if (q_next == q_end) { /* wave-uniform */
+                if (exhausted) break;
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(work_queue, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                const uint32_t limit = MODE == MODE_PHASE2 ? n_cont : total_slots;
+                if (c * 64u >= limit) { exhausted = true; break; }
+                q_next = c * 64u;
+                q_end = q_next + 64u < limit ? q_next + 64u : limit;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            uint32_t avail = q_end - q_next;
+            uint32_t probe_slot = 0u;
+            if (MODE == MODE_COST) {
+                const uint32_t chunk = wave * 64u + lane;
+                const uint32_t first = chunk * 64u;
+                const uint32_t last = first + 64u < total_slots ? first + 64u : total_slots;
+                probe_slot = first + ((last > first ? last - first : 0u) >> 1) + 4u < last ? first + ((last - first) >> 1) + 4u : first;
+                avail = chunk < fr.n_chunks ? 64u : rank; /* lanes beyond the last chunk get nothing */
+                cost_started = true;
+            }
+            if (phase == PH_DONE && rank < avail) {
+                const uint32_t slot = MODE == MODE_COST ? probe_slot : q_next + rank;
+                if (MODE == MODE_PHASE2) {
+                    const uint32_t *rec = qs.cont_buf + (size_t)slot * cont_stride;
+                    LOAD_CONT(rec);
+                } else {
+                    const uint32_t band = slot / band_slots;
+                    const uint32_t r = slot - band * band_slots;
+                    const uint32_t rows_left = fr.rows - (band << 3);
+                    const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
+                    const uint32_t col = r / band_rows;
+                    const uint32_t row = (band << 3) + (r - col * band_rows);
+                    out_index = row * fr.cols + col;
+                    /* main.rs:1093-1096 + Camera::shoot (main.rs:84-99) with the per-frame basis hoisted to the host */
+                    const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+                    const float clip_y = (fr.half_height - (float)y) / fr.height_f;
+                    const float clip_x = ((float)x - fr.half_width) / fr.height_f;
+                    const V3 cx = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
+                    const V3 cy = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
+                    const V3 ct = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
+                    req.o = v3(fr.cam_origin[0], fr.cam_origin[1], fr.cam_origin[2]);
+                    req.d = normalize(clip_x * cx + clip_y * cy + ct);
+                    req.mode = FACE_FRONT;
+                    req.excl = 0u;
+                    /* TraceState { depth: max_depth, contribution: 1.0 } (main.rs:1097-1100); the entry check
+                     * of ray_trace (main.rs:469) always passes at the root */
+                    contribution = 1.0f;
+                    sp = 0;
+                    phase = PH_NODE;
+                }
+            }
+            if (MODE == MODE_COST) {
+                q_next = q_end;
+                need = 0ull;
+            } else {
+                const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+                q_next += n_need < avail ? n_need : avail;
+                need = __builtin_amdgcn_ballot_w64(phase == PH_DONE);
+            }
+        }
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(phase != PH_DONE);
+        if (active == 0ull) break;
+        if (MODE == MODE_PHASE1 && iteration >= qs.evict_min_iterations &&
+            (uint32_t)__builtin_popcountll(active) <= qs.evict_threshold) {
+            /* Few lanes left: a wave that keeps going runs the full intersection loop for a handful of
+             * rays.  Park their state in the continuation queue (one wave-aggregated atomic) and leave;
+             * phase 2 packs 64 of these per wave. */
+            const uint32_t n_act = (uint32_t)__builtin_popcountll(active);
+            uint32_t base = 0u;
+            if (lane == 0u) base = atomicAdd(qs.cont_count, n_act);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (phase != PH_DONE) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u));
+                uint32_t *rec = qs.cont_buf + (size_t)(base + rank) * cont_stride;
+                STORE_CONT(rec);
+            }
+            break;
+        }
+        iteration += 1u;
+#ifdef RT_WAVE_PRIORITY /* measured slower (profiles/README.md): any extra code here tips the compiler's allocation of the loop */
+        /* The frame's critical path is its deepest pixel: ~50 dependent casts in one wave, each of which
+         * takes 4x longer while three other waves share the SIMD.  Waves that turn out to be long raise their
+         * issue priority step by step, so they run at close to solo speed and the short waves fill the gaps. */
+        {
+            /* s_setprio is a scalar instruction: it must sit under a branch the compiler knows to be
+             * wave-uniform (readfirstlane), or it runs every trip regardless of the condition */
+            const uint32_t it_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)iteration);
+            if (it_u == RT_PRIO_STEP1) __builtin_amdgcn_s_setprio(1);
+            if (it_u == RT_PRIO_STEP2) __builtin_amdgcn_s_setprio(2);
+            if (it_u == RT_PRIO_STEP3) __builtin_amdgcn_s_setprio(3);
+        }
+#endif
+
         CastResult cr;
         cr.prim = -1;
         cr.t = 0.0f;
@@ -416,6 +710,12 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         if (phase != PH_DONE) {
 #ifdef RT_CAST_PIPELINED /* experiment: compiler-generated SGPR double buffering; slower than the plain loop (profiles/README) */
             cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_pipelined(sc, req);
+#elif defined(RT_CAST_BULK)
+            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_bulk(sc, req);
+#elif defined(RT_CAST_OUTLINED)
+            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req)
+                         : cast_outlined(sc.tris, sc.n_triangles, sc.spheres, sc.n_spheres, req.o.x, req.o.y, req.o.z, req.d.x, req.d.y,
+                                         req.d.z, req.mode, req.excl);
 #else
             cr = cast<USE_LDS>(sc, lds_tris, req);
 #endif
@@ -436,7 +736,22 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             V3 i_in_dir = req.d;
             uint32_t i_in_mode = req.mode;
 
-            if (phase == PH_NODE) {
+            if (MODE == MODE_COST) {
+                /* The probe stops after its primary cast and grades the tile by what it hit: transparent
+                 * surfaces spawn both children at every level (dozens of casts), mirrors one child, diffuse
+                 * surfaces only their shadow rays.  A coarse class is enough to start the long tiles first. */
+                uint32_t cls = 0u;
+                if (cr.prim >= 0) {
+                    const uint32_t obj = (uint32_t)cr.prim < sc.n_triangles ? sc.tris[cr.prim].obj : sc.spheres[(uint32_t)cr.prim - sc.n_triangles].obj;
+                    const rt_material &rm = sc.materials[obj];
+                    const float rc = rm.shiness * (1.0f - rm.transparency);
+                    cls = 1u;
+                    if (fr.max_depth > 0 && rc >= THRESHOLD) cls = 2u;
+                    if (fr.max_depth > 0 && rm.transparency > THRESHOLD) cls = rc >= THRESHOLD ? 4u : 3u;
+                }
+                qs.tile_cost[wave * 64u + lane] = cls;
+                phase = PH_DONE;
+            } else if (phase == PH_NODE) {
                 if (cr.prim < 0) {
                     value = v3(0.0f, 0.0f, 0.0f); /* main.rs:475 */
                     go = GO_RETURN;
@@ -503,7 +818,7 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             }
 
             /* small per-lane control loop; every path ends in a new cast request or PH_DONE */
-            for (;;) {
+            for (; MODE != MODE_COST;) {
                 if (go == GO_NEXT_LIGHT) {
                     /* the `for light in &self.lights` loop of get_shade up to the shadow cast (main.rs:413-433) */
                     bool issued = false;
@@ -620,7 +935,11 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
                     break;
                 } else { /* GO_RETURN: unwind finished activations */
                     if (sp == 0) {
-                        pixel = value;
+                        /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
+                        float *px = out + (size_t)out_index * 3u;
+                        px[0] = 0.0f + value.x;
+                        px[1] = 0.0f + value.y;
+                        px[2] = 0.0f + value.z;
                         phase = PH_DONE;
                         break;
                     }
@@ -649,15 +968,17 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         }
     }
 
-    if (in_image) {
-        /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
-        float *px = out + ((size_t)row * fr.cols + col) * 3u;
-        px[0] = 0.0f + pixel.x;
-        px[1] = 0.0f + pixel.y;
-        px[2] = 0.0f + pixel.z;
+#ifdef RT_DIAG_TIMELINE
+    if (qs.timeline != nullptr && MODE == MODE_STATIC && lane == 0u) {
+        const unsigned long long diag_t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *rec = qs.timeline + (size_t)wave * 4u;
+        rec[0] = diag_t0;
+        rec[1] = diag_t1;
+        rec[2] = iteration;
+        rec[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); /* HW_REG_HW_ID */
     }
-
-    if (ray_count != nullptr) {
+#endif
+    if (ray_count != nullptr && MODE != MODE_COST) {
         uint32_t c = casts;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
         if (lane == 0u && c != 0u) atomicAdd(ray_count, (unsigned long long)c);
@@ -670,27 +991,86 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
 
 namespace rt {
 
-template <int MAXD>
-static hipError_t launch_maxd(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
-                              hipStream_t stream, bool use_lds) {
-    const uint32_t tiles = ((fr.cols + 7u) >> 3) * ((fr.rows + 7u) >> 3);
+/* Order the chunks by probe cost, most expensive first (counting sort on min(cost, 255); one workgroup).
+ * Scheduling only: any permutation gives the same image. */
+__global__ __launch_bounds__(1024) void order_chunks_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t base[256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[cost[i] < 255u ? cost[i] : 255u], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0u;
+        for (int k = 255; k >= 0; --k) { base[k] = acc; acc += hist[k]; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t k = cost[i] < 255u ? cost[i] : 255u;
+        order[atomicAdd(&base[k], 1u)] = i;
+    }
+}
+
+template <int MAXD, int MODE>
+static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                              const KernelQueues &qs, uint32_t waves, hipStream_t stream, bool use_lds) {
+    if (waves == 0u) return hipSuccess;
     const uint32_t waves_per_block = RT_BLOCK_THREADS / 64;
-    const uint32_t blocks = (tiles + waves_per_block - 1) / waves_per_block;
-    if (blocks == 0) return hipSuccess;
+    const uint32_t blocks = (waves + waves_per_block - 1) / waves_per_block;
     if (use_lds) {
         const size_t lds = (size_t)sc.n_triangles * sizeof(DevTri);
-        hipLaunchKernelGGL((whitted_kernel<MAXD, true>), dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, sc, fr, out, ray_count);
+        hipLaunchKernelGGL((whitted_kernel<MAXD, true, MODE>), dim3(blocks), dim3(RT_BLOCK_THREADS), lds, stream, sc, fr, out, ray_count, qs);
     } else {
-        hipLaunchKernelGGL((whitted_kernel<MAXD, false>), dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, sc, fr, out, ray_count);
+        hipLaunchKernelGGL((whitted_kernel<MAXD, false, MODE>), dim3(blocks), dim3(RT_BLOCK_THREADS), 0, stream, sc, fr, out, ray_count, qs);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
-                          hipStream_t stream, int variant) {
+template <int MAXD>
+static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const KernelQueues &qs,
+                              uint32_t resident_waves, hipStream_t stream, int variant) {
     const bool use_lds = (variant & RT_VARIANT_LDS) != 0 && (size_t)sc.n_triangles * sizeof(DevTri) <= RT_LDS_SCENE_LIMIT;
-    if (fr.max_depth <= 8) return launch_maxd<8>(sc, fr, out, ray_count, stream, use_lds);
-    return launch_maxd<RT_MAX_DEPTH>(sc, fr, out, ray_count, stream, use_lds);
+    const uint32_t total = fr.cols * fr.rows;
+    fr.n_chunks = (total + 63u) / 64u;
+    const int scheme = variant & RT_VARIANT_SCHEME_MASK;
+    if (scheme == RT_VARIANT_STATIC) {
+        KernelQueues q2 = qs;
+        q2.tile_order = nullptr;
+        return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
+    }
+    if (scheme == RT_VARIANT_SORTED) {
+        /* 1. probe one pixel per chunk, 2. order chunks by probe cost, 3. render, most expensive chunks first */
+        if (fr.n_chunks <= resident_waves || qs.tile_order == nullptr) { /* everything is resident at once: order is moot */
+            KernelQueues q2 = qs;
+            q2.tile_order = nullptr;
+            return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
+        }
+        hipError_t e = launch_mode<MAXD, MODE_COST>(sc, fr, out, ray_count, qs, (fr.n_chunks + 63u) / 64u, stream, use_lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(1024), 0, stream, qs.tile_cost, qs.tile_order, fr.n_chunks);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
+    }
+    if (scheme == RT_VARIANT_PERSISTENT) {
+        const uint32_t waves = fr.n_chunks < resident_waves ? fr.n_chunks : resident_waves;
+        return launch_mode<MAXD, MODE_PERSISTENT>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
+    }
+    /* two-phase (default): coherent tiles that evict their stragglers, then the stragglers packed 64 per wave */
+    hipError_t e = launch_mode<MAXD, MODE_PHASE1>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
+    if (e != hipSuccess) return e;
+    const uint32_t max_cont_waves = (qs.cont_capacity + 63u) / 64u;
+    const uint32_t waves = max_cont_waves < resident_waves ? max_cont_waves : resident_waves;
+    return launch_mode<MAXD, MODE_PHASE2>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
+}
+
+uint32_t cont_record_dwords(int32_t max_depth) { return CONT_FIXED + FRAME_DWORDS * (uint32_t)(max_depth <= 8 ? 8 : RT_MAX_DEPTH); }
+
+/* qs.work_queue and qs.cont_count must be zero; resident_waves: CUs * 4 * RT_MIN_WAVES */
+hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                          const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant) {
+    if (fr.max_depth <= 8) return launch_maxd<8>(sc, fr, out, ray_count, qs, resident_waves, stream, variant);
+    return launch_maxd<RT_MAX_DEPTH>(sc, fr, out, ray_count, qs, resident_waves, stream, variant);
 }
 
 } /* namespace rt */

@@ -190,12 +190,22 @@ int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const
 
 /* ---- diagnostics ------------------------------------------------------------ */
 
-/* Kernel variant used by the render entry points of this process:
- *   0  triangle records fetched with wave-uniform scalar loads (SGPR broadcast)
- *   1  triangle records staged in LDS once per workgroup (LDS broadcast)
+/* Kernel variant used by the render entry points of this process (bit field):
+ *   bit 0     0: triangle records fetched with wave-uniform scalar loads (SGPR broadcast)
+ *             1: triangle records staged in LDS once per workgroup (LDS broadcast)
+ *   bits 1-2  0: one 8x8 tile per wave, tiles dispatched most-expensive-first: a probe traces one pixel
+ *                per tile, a counting sort orders the tiles by the probe's cast count (default)
+ *             2: one 8x8 tile per wave, dispatched in image order
+ *             4: persistent waves, lanes refill pixel by pixel from a work queue
+ *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
  * Default 0, or the value of the RT_AMD_VARIANT environment variable at load. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);
+
+/* Two-phase (variant 6) tuning: a tile wave parks its remaining lanes once at most `threshold` (0..63) are active
+ * and it has done at least `min_iterations` casts.  Defaults 16 / 4 (RT_AMD_EVICT_THRESHOLD,
+ * RT_AMD_EVICT_MIN_ITER).  Changes scheduling only, never results. */
+int rt_set_eviction(int threshold, int min_iterations);
 
 /* The deterministic f32 math the path computes with (csrc/rt_detmath.h),
  * evaluated element-wise on the host or on the device, so tests can prove the

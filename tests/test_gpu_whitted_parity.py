@@ -27,7 +27,10 @@ def _compare(world, camera, scene, frame, variant=0):
     from homework_18_graphics_raytracer_amd import _capi
 
     _capi.check(_capi.amd_lib().rt_set_variant(variant))
-    got, casts = rt.render_whitted_numpy(scene, camera, frame)
+    try:
+        got, casts = rt.render_whitted_numpy(scene, camera, frame)
+    finally:
+        _capi.check(_capi.amd_lib().rt_set_variant(0))
     want, want_casts = _oracle.render_whitted(world.desc(), camera, frame)
     diff = got.view(np.uint32) != want.view(np.uint32)
     if diff.any():
@@ -40,11 +43,31 @@ def _compare(world, camera, scene, frame, variant=0):
     return got, casts
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("w,h,depth", [(256, 256, 1), (320, 240, 5), (200, 150, 8), (97, 61, 0), (64, 64, 3)])
 def test_whitted_bit_exact(ctx, w, h, depth, variant):
     world, camera, scene = ctx
     _compare(world, camera, scene, rt.Frame.full(w, h, depth), variant)
+
+
+@pytest.mark.parametrize("threshold,min_iter", [(0, 0), (63, 0), (63, 1), (32, 2), (8, 10)])
+def test_two_phase_eviction_settings_do_not_change_results(ctx, threshold, min_iter):
+    """Eviction only moves work between the two passes; any setting must give the same bits and cast count."""
+    from homework_18_graphics_raytracer_amd import _capi
+
+    world, camera, scene = ctx
+    _capi.check(_capi.amd_lib().rt_set_eviction(threshold, min_iter))
+    try:
+        _compare(world, camera, scene, rt.Frame.full(200, 150, 8), 6)
+    finally:
+        _capi.check(_capi.amd_lib().rt_set_eviction(16, 4))
+
+
+def test_sorted_dispatch_on_a_frame_larger_than_the_resident_grid(ctx):
+    """The cost probe + sorted order only engages when there are more tiles than resident waves."""
+    world, camera, scene = ctx
+    _compare(world, camera, scene, rt.Frame.full(1000, 600, 8), 0)
+    _compare(world, camera, scene, rt.Frame.full(1003, 597, 3), 0)  # ragged last band and last chunk
 
 
 def test_whitted_reference_size_bit_exact(ctx):

@@ -37,15 +37,18 @@ desc = world.desc()
 frame = rt.Frame.full(args.width, args.height, args.depth)
 libs = {}
 for tag in args.tags.split(","):
-    path = _capi.PKG_DIR / ("librt_amd.so" if tag == "main" else f"variants/librt_amd_{tag}.so")
+    parts = tag.split(":")  # "name", "name:variant" or "name:variant:evict_threshold:evict_min_iter"
+    name, var = parts[0], (parts[1] if len(parts) > 1 else "")
+    evict = (int(parts[2]), int(parts[3])) if len(parts) > 3 else None
+    path = _capi.PKG_DIR / ("librt_amd.so" if name == "main" else f"variants/librt_amd_{name}.so")
     lib = C.CDLL(str(path))
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_scene_create.argtypes = [C.POINTER(_capi.SceneDesc), C.POINTER(C.c_void_p)]
     lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(_capi.Camera), C.POINTER(_capi.Frame), C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.rt_set_variant(args.variant)
+    lib_variant = int(var) if var else args.variant
     h = C.c_void_p()
     assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0, lib.rt_last_error()
-    libs[tag] = (lib, h)
+    libs[tag] = (lib, h, lib_variant, evict)
 
 out = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -53,7 +56,10 @@ stream = torch.cuda.current_stream().cuda_stream
 
 
 def run(tag, n):
-    lib, h = libs[tag]
+    lib, h, lib_variant, evict = libs[tag]
+    lib.rt_set_variant(lib_variant)
+    if evict is not None:
+        lib.rt_set_eviction(*evict)
     for _ in range(n):
         rc = lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(stream))
         assert rc == 0, lib.rt_last_error()
