@@ -25,7 +25,7 @@ from ._capi import Camera, Frame, Light, Material, RtError, SceneDesc, Sphere, T
 
 __all__ = [
     "World", "ObjectProxy", "Scene", "Camera", "Frame", "Material", "Light", "RtError", "reference_world",
-    "reference_camera", "render_whitted", "render_whitted_numpy", "post_process", "encode_srgb8", "write_to_file",
+    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "post_process", "encode_srgb8", "write_to_file",
     "DEFAULT_OBJ",
 ]
 
@@ -177,6 +177,57 @@ def render_whitted_numpy(scene: Scene, camera: Camera, frame: Frame):
         _capi.amd_lib().rt_render_whitted_host(scene._h, C.byref(camera), C.byref(frame), img.ctypes.data_as(C.c_void_p), C.byref(casts))
     )
     return img, int(casts.value)
+
+
+class Rng:
+    """Device-resident per-pixel IsaacRng states of one tile (src/main.rs:1117-1127); rt_rng_create/destroy."""
+
+    def __init__(self, frame: Frame):
+        self.frame = frame
+        self._h = C.c_void_p()
+        _capi.check(_capi.amd_lib().rt_rng_create(C.byref(frame), C.byref(self._h)))
+
+    def download(self) -> np.ndarray:
+        words = _capi.amd_lib().rt_rng_state_words()
+        st = np.empty((self.frame.rows * self.frame.cols, words), dtype=np.uint32)
+        _capi.check(_capi.amd_lib().rt_rng_download(self._h, st.ctypes.data_as(C.c_void_p)))
+        return st
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _capi.amd_lib().rt_rng_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_distributed(scene: Scene, camera: Camera, frame: Frame, rng: Rng, n_epochs: int = 1, focus: float = 3.0,
+                       blur: float = 0.04, accum=None, samples=None, valid=None, ray_count=None, stream=None):
+    """`n_epochs` passes of the distributed/DoF closure (src/main.rs:1131-1161) over one tile, on the device.
+
+    accum   (rows, cols, 3) f32 CUDA tensor or None: surviving samples are added in epoch order.
+    samples (n_epochs, rows, cols, 3) f32 / valid (n_epochs, rows, cols) u8 CUDA tensors or None: raw samples + filter.
+    """
+    import torch
+
+    def ptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    rows, cols = frame.rows, frame.cols
+    for t, shape, dt in ((accum, (rows, cols, 3), torch.float32), (samples, (n_epochs, rows, cols, 3), torch.float32),
+                         (valid, (n_epochs, rows, cols), torch.uint8)):
+        if t is not None and not (t.is_cuda and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"expected a contiguous CUDA {dt} tensor of shape {shape}")
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _capi.check(
+        _capi.amd_lib().rt_render_distributed(scene._h, C.byref(camera), C.byref(frame), float(focus), float(blur), rng._h,
+                                              int(n_epochs), ptr(accum), ptr(samples), ptr(valid), ptr(ray_count), C.c_void_p(s.cuda_stream))
+    )
+    return accum if accum is not None else samples
 
 
 def post_process(img: np.ndarray) -> float:

@@ -284,6 +284,8 @@ static int make_kernel_frame(const rt_camera *camera, const rt_frame *frame, rt:
     kf->cam_x[0] = x.x; kf->cam_x[1] = x.y; kf->cam_x[2] = x.z;
     kf->cam_y[0] = y.x; kf->cam_y[1] = y.y; kf->cam_y[2] = y.z;
     kf->cam_toward[0] = toward.x; kf->cam_toward[1] = toward.y; kf->cam_toward[2] = toward.z;
+    const V3 origin_focus = rt::v3p(camera->center) + rt::normalize(toward) * camera->near; /* main.rs:118-119 */
+    kf->cam_origin_focus[0] = origin_focus.x; kf->cam_origin_focus[1] = origin_focus.y; kf->cam_origin_focus[2] = origin_focus.z;
     return RT_OK;
 }
 
@@ -376,6 +378,86 @@ int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const
     if (d_cnt) (void)hipFree(d_cnt);
     if (rc != RT_OK) return rc;
     if (e != hipSuccess) return fail_hip("rt_render_whitted_host", e);
+    return RT_OK;
+}
+
+/* ---- distributed pass ------------------------------------------------------- */
+
+struct rt_rng {
+    int device;
+    uint32_t *d_states;
+    uint32_t cols, rows, x0, y0, y_step;
+};
+
+int rt_rng_state_words(void) { return (int)RT_RNG_STATE_WORDS; }
+
+int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
+    if (!out_rng) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_create: null argument");
+    *out_rng = nullptr;
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_create: bad frame");
+    rt_rng *r = new (std::nothrow) rt_rng();
+    if (!r) return fail(RT_ERR_OUT_OF_MEMORY, "rt_rng_create: host allocation failed");
+    r->cols = frame->x1 - frame->x0;
+    r->rows = rt_frame_rows(frame);
+    r->x0 = frame->x0;
+    r->y0 = frame->y0;
+    r->y_step = frame->y_step;
+    r->d_states = nullptr;
+    const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_STATE_WORDS * sizeof(uint32_t);
+    hipError_t e = hipGetDevice(&r->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
+    if (e == hipSuccess) {
+        rt::KernelFrame kf;
+        memset(&kf, 0, sizeof kf);
+        kf.cols = r->cols; kf.rows = r->rows; kf.x0 = r->x0; kf.y0 = r->y0; kf.y_step = r->y_step;
+        e = rt::launch_rng_seed(r->d_states, kf, nullptr);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (r->d_states) (void)hipFree(r->d_states);
+        delete r;
+        return fail_hip("rt_rng_create", e);
+    }
+    *out_rng = r;
+    return RT_OK;
+}
+
+int rt_rng_destroy(rt_rng *rng) {
+    if (!rng) return RT_OK;
+    hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
+    delete rng;
+    if (e != hipSuccess) return fail_hip("rt_rng_destroy: hipFree", e);
+    return RT_OK;
+}
+
+int rt_rng_download(const rt_rng *rng, uint32_t *h_states) {
+    if (!rng || !h_states) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_download: null argument");
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(h_states, rng->d_states, (size_t)rng->cols * rng->rows * RT_RNG_STATE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
+                          rt_rng *rng, uint32_t n_epochs, float *d_accum, float *d_samples, unsigned char *d_valid,
+                          unsigned long long *d_ray_count, void *hip_stream) {
+    if (!scene || !rng) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_distributed: null argument");
+    if (!d_accum && !d_samples) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_distributed: need d_accum or d_samples");
+    rt::KernelFrame kf;
+    int rc = make_kernel_frame(camera, frame, &kf);
+    if (rc != RT_OK) return rc;
+    if (kf.cols != rng->cols || kf.rows != rng->rows || kf.x0 != rng->x0 || kf.y0 != rng->y0 || kf.y_step != rng->y_step)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_distributed: the RNG was created for a different tile");
+    rt::DistParams dp;
+    dp.rng_states = rng->d_states;
+    dp.n_epochs = n_epochs;
+    dp.focus = focus;
+    dp.blur = blur;
+    dp.accum = d_accum;
+    dp.samples = d_samples;
+    dp.valid = d_valid;
+    dp.ray_count = d_ray_count;
+    hipError_t e = rt::launch_distributed(scene->ks, kf, dp, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
     return RT_OK;
 }
 

@@ -1,0 +1,160 @@
+/*
+ * rt_cast.h — device-side World::cast (main.rs:180-326) and the hit record, shared by the Whitted kernel
+ * (rt_kernels.hip) and the distributed-pass kernel (rt_distributed.hip).  Device code only.
+ */
+#ifndef RT_CAST_H
+#define RT_CAST_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_device_scene.h"
+#include "rt_shade.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+/* ---- ray / hit records ------------------------------------------------------ */
+
+enum : uint32_t { FACE_FRONT = 0u, FACE_BACK = 1u, FACE_BOTH = 2u }; /* main.rs:52-57 */
+
+/* Packed exclusion (main.rs:77-81): 0 = None, else
+ *   bit 31 = Some, bits 29..30 = face direction, bits 0..28 = primitive id.
+ * Primitive ids: triangle i -> i, sphere i -> n_triangles + i (PrimitiveIndex, primitives.rs:31-34). */
+__device__ __forceinline__ uint32_t pack_excl(uint32_t prim, uint32_t face) { return 0x80000000u | (face << 29) | prim; }
+
+struct Ray {
+    V3 o, d;
+    uint32_t mode; /* FaceDirection of the ray (culling mode) */
+    uint32_t excl; /* packed exclusion */
+};
+
+struct CastResult {
+    float t;       /* travel distance of the nearest hit */
+    int32_t prim;  /* -1 = miss */
+    uint32_t bf;   /* backface flag of the hit */
+    float a0, a1, a2; /* triangle hits: the three signed areas (main.rs:218-222) */
+};
+
+/* World::cast, main.rs:180-326.  Convergent: `i` is wave-uniform. */
+template <bool USE_LDS>
+__device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *__restrict__ lds_tris, const Ray &ray) {
+    CastResult best;
+    best.prim = -1;
+    best.t = 0.0f;
+    best.bf = 0u;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    bool have = false;
+
+    const bool cull_back = ray.mode == FACE_FRONT;  /* skip backfaces  (main.rs:185) */
+    const bool cull_front = ray.mode == FACE_BACK;  /* skip frontfaces (main.rs:186) */
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+
+    const uint32_t nt = sc.n_triangles;
+    const DevTri *__restrict__ tris = USE_LDS ? lds_tris : sc.tris;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const DevTri &T = tris[i];
+        const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+        const float nd = dot(n, ray.d);
+        const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
+        if (bf ? cull_back : cull_front) continue;
+        if (ex_some && ex_prim == i) { /* main.rs:190-200 */
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        const float t = (T.d - dot(n, ray.o)) / nd; /* main.rs:203-204 */
+        if (t <= 0.0f) continue;                     /* NaN passes, as in the reference */
+        const V3 p = ray.o + ray.d * t;
+        const V3 v0 = v3(T.v0[0], T.v0[1], T.v0[2]);
+        const V3 v1 = v3(T.v1[0], T.v1[1], T.v1[2]);
+        const V3 v2 = v3(T.v2[0], T.v2[1], T.v2[2]);
+        const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v1), n);
+        const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v2), n);
+        const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v0), n);
+        if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue; /* NaN areas pass (main.rs:224) */
+        if (have && best.t < t) continue;                  /* ties: the later primitive wins */
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)i;
+        best.bf = bf ? 1u : 0u;
+        best.a0 = a0; best.a1 = a1; best.a2 = a2;
+    }
+
+    const uint32_t ns = sc.n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
+        const DevSphere &S = sc.spheres[i];
+        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
+        const V3 disp = c - ray.o;
+        const float lsd = magnitude(cross(disp, ray.d));
+        if (lsd > S.radius) continue;
+        const float tc = dot(ray.d, disp);
+        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
+        float t;
+        bool bf;
+        if (ray.mode == FACE_FRONT) { t = tc - k; bf = false; }
+        else if (ray.mode == FACE_BACK) { t = tc + k; bf = true; }
+        else if (tc < k) { t = tc + k; bf = true; }
+        else { t = tc - k; bf = false; }
+        if (t <= 0.0f) continue;
+        if (ex_some && ex_prim == nt + i) {
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        if (have && best.t < t) continue;
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)(nt + i);
+        best.bf = bf ? 1u : 0u;
+    }
+    return best;
+}
+
+/* What the state machine keeps of a Hit (main.rs:139-147). */
+struct HitGeom {
+    V3 pos, normal;
+    float u, v;
+    uint32_t prim, bf, obj;
+};
+
+/* The tail of the accept branches of World::cast (main.rs:235-252, 304-313),
+ * evaluated once for the winning primitive instead of on every improvement. */
+__device__ __forceinline__ HitGeom finish_hit(const KernelScene &sc, const Ray &ray, const CastResult &r, bool want_sphere_uv_always) {
+    HitGeom h;
+    h.prim = (uint32_t)r.prim;
+    h.bf = r.bf;
+    h.pos = ray.o + ray.d * r.t;
+    if ((uint32_t)r.prim < sc.n_triangles) {
+        const DevTri &T = sc.tris[r.prim];
+        const DevTriAttr &A = sc.attrs[r.prim];
+        h.obj = T.obj;
+        const V3 bary = v3(r.a0, r.a1, r.a2) / T.area;
+        /* Matrix3::from_cols(n0,n1,n2) * bary: rows dotted with bary */
+        const V3 tmp = v3(dot(v3(A.n0[0], A.n1[0], A.n2[0]), bary),
+                          dot(v3(A.n0[1], A.n1[1], A.n2[1]), bary),
+                          dot(v3(A.n0[2], A.n1[2], A.n2[2]), bary));
+        h.normal = r.bf ? -tmp : tmp;
+        h.u = (A.uv0x * bary.x + A.uv1x * bary.y) + A.uv2x * bary.z;
+        h.v = (A.uv0y * bary.x + A.uv1y * bary.y) + A.uv2y * bary.z;
+    } else {
+        const DevSphere &S = sc.spheres[(uint32_t)r.prim - sc.n_triangles];
+        h.obj = S.obj;
+        const V3 tmp = normalize(h.pos - v3(S.c[0], S.c[1], S.c[2]));
+        h.normal = r.bf ? -tmp : tmp;
+        h.u = 0.0f;
+        h.v = 0.0f;
+        /* uv (main.rs:310-313) costs an acos and an atan2 and is only read by
+         * generative materials: evaluate it only for those (pure, so identical) */
+        if (want_sphere_uv_always || material_reads_uv(sc.materials[h.obj])) {
+            h.u = rtdm::acosf(h.normal.y) / RT_F_PI;
+            h.v = rtdm::atan2f(h.normal.z, h.normal.x) / (RT_F_PI * 2.0f) + 0.5f;
+        }
+    }
+    return h;
+}
+
+} /* namespace rt */
+
+#endif /* RT_CAST_H */

@@ -1,0 +1,533 @@
+/*
+ * rt_distributed.hip — the stochastic ("distributed") pass as a HIP kernel for gfx950.
+ *
+ * Replaces the par_iter_mut closure at src/main.rs:1131-1156: per pixel and epoch,
+ *   shoot_focus (2 Gaussian draws, main.rs:101-127) -> cast -> distributed_ray_trace (main.rs:521-614),
+ * with the per-pixel IsaacRng (seeded y*2^33 + x, main.rs:1117-1127) resident in HBM and its stream
+ * continuing across epochs.  The sample filter of main.rs:1157-1160 (drop unless all three channels
+ * are is_normal) and `img[at] += photon` (main.rs:1165) are fused into the kernel.
+ *
+ * distributed_ray_trace is a chain, not a tree (one scattered ray per level), so the per-lane state
+ * machine is: cast -> [select + scatter] -> cast next -> shade next (3 shadow casts) -> descend ...,
+ * then unwind `get_shade(next).mix(x * brdf, 0.5)` / `(x + get_shade(next)) * decay` through a small
+ * frame stack.  Every cast of every lane goes through the same wave-convergent intersection loop as the
+ * Whitted kernel (rt_cast.h).  get_shade(&hit) at main.rs:524 is pure and only used at depth <= 0; it is
+ * evaluated there only (the oracle follows the same plan, so cast counts agree).
+ *
+ * rand 0.5 (ISAAC-32, Uniform<f32>, ziggurat Normal) is restated from the crate's published algorithms;
+ * the crate is not in the build image, so the random bit streams are "parity unpinned" against the Rust
+ * binary and pinned bit-for-bit against oracle/rt_oracle.cpp, which implements them independently.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_cast.h"
+#include "rt_ziggurat_tables.h"
+
+namespace rt {
+
+/* ---- per-pixel RNG record in HBM: mem[256], a, b, c, results[256], index (the oracle's layout) ---- */
+enum : uint32_t { RNG_MEM = 0u, RNG_A = 256u, RNG_B = 257u, RNG_C = 258u, RNG_RESULTS = 259u, RNG_INDEX = 515u, RNG_WORDS = 516u };
+
+__device__ const double ZIG_X[257] = RT_ZIG_NORM_X;
+__device__ const double ZIG_F[257] = RT_ZIG_NORM_F;
+
+/* IsaacCore::init(key, rounds = 1) as called by IsaacRng::new_from_u64(seed) */
+__device__ void isaac_seed(uint32_t *st, unsigned long long seed) {
+    for (uint32_t i = 0; i < 256u; ++i) st[RNG_MEM + i] = 0u;
+    st[RNG_MEM + 0] = (uint32_t)seed;
+    st[RNG_MEM + 1] = (uint32_t)(seed >> 32);
+    uint32_t a = 0x1367df5au, b = 0x95d90059u, c = 0xc3163e4bu, d = 0x0f421ad8u;
+    uint32_t e = 0xd92a4a78u, f = 0xa51a3c49u, g = 0xc4efea1bu, h = 0x30609119u;
+    for (uint32_t i = 0; i < 256u; i += 8u) {
+        a += st[i]; b += st[i + 1]; c += st[i + 2]; d += st[i + 3];
+        e += st[i + 4]; f += st[i + 5]; g += st[i + 6]; h += st[i + 7];
+        a ^= b << 11; d += a; b += c;
+        b ^= c >> 2;  e += b; c += d;
+        c ^= d << 8;  f += c; d += e;
+        d ^= e >> 16; g += d; e += f;
+        e ^= f << 10; h += e; f += g;
+        f ^= g >> 4;  a += f; g += h;
+        g ^= h << 8;  b += g; h += a;
+        h ^= a >> 9;  c += h; a += b;
+        st[i] = a; st[i + 1] = b; st[i + 2] = c; st[i + 3] = d;
+        st[i + 4] = e; st[i + 5] = f; st[i + 6] = g; st[i + 7] = h;
+    }
+    st[RNG_A] = 0u;
+    st[RNG_B] = 0u;
+    st[RNG_C] = 0u;
+    for (uint32_t i = 0; i < 256u; ++i) st[RNG_RESULTS + i] = 0u;
+    st[RNG_INDEX] = 256u;
+}
+
+/* IsaacCore::generate; results stored backwards (read forwards = the reference implementation's order) */
+__device__ void isaac_generate(uint32_t *st) {
+    const uint32_t cc = st[RNG_C] + 1u;
+    st[RNG_C] = cc;
+    uint32_t a = st[RNG_A], b = st[RNG_B] + cc;
+    for (uint32_t i = 0; i < 256u; ++i) {
+        const uint32_t x = st[RNG_MEM + i];
+        const uint32_t sel = i & 3u;
+        const uint32_t mixv = sel == 0u ? (a ^ (a << 13)) : sel == 1u ? (a ^ (a >> 6)) : sel == 2u ? (a ^ (a << 2)) : (a ^ (a >> 16));
+        a = mixv + st[RNG_MEM + ((i + 128u) & 255u)];
+        const uint32_t y = a + b + st[RNG_MEM + ((x >> 2) & 255u)];
+        st[RNG_MEM + i] = y;
+        b = x + st[RNG_MEM + ((y >> 10) & 255u)];
+        st[RNG_RESULTS + 255u - i] = b;
+    }
+    st[RNG_A] = a;
+    st[RNG_B] = b;
+}
+
+/* BlockRng over the record; `index` lives in a register while a lane works and is stored back at the end */
+struct Rng {
+    uint32_t *st;
+    uint32_t index;
+};
+__device__ __forceinline__ uint32_t next_u32(Rng &r) {
+    if (r.index >= 256u) { isaac_generate(r.st); r.index = 0u; }
+    return r.st[RNG_RESULTS + r.index++];
+}
+__device__ __forceinline__ unsigned long long next_u64(Rng &r) {
+    if (r.index < 255u) {
+        const unsigned long long x = r.st[RNG_RESULTS + r.index], y = r.st[RNG_RESULTS + r.index + 1u];
+        r.index += 2u;
+        return (y << 32) | x;
+    } else if (r.index >= 256u) {
+        isaac_generate(r.st);
+        r.index = 2u;
+        return ((unsigned long long)r.st[RNG_RESULTS + 1] << 32) | r.st[RNG_RESULTS + 0];
+    } else {
+        const unsigned long long x = r.st[RNG_RESULTS + 255];
+        isaac_generate(r.st);
+        r.index = 1u;
+        return ((unsigned long long)r.st[RNG_RESULTS + 0] << 32) | x;
+    }
+}
+/* rand 0.5 UniformFloat<f32>::sample_single: 23 random bits -> [1,2), then * scale + offset */
+__device__ __forceinline__ float gen_range_f32(Rng &r, float low, float high) {
+    const float scale = high - low;
+    const float offset = low - scale;
+    const float value1_2 = rtdm::f32_from_bits((next_u32(r) >> 9) | 0x3f800000u);
+    return value1_2 * scale + offset;
+}
+__device__ __forceinline__ double open01_f64(Rng &r) {
+    const unsigned long long fraction = next_u64(r) >> 12;
+    return rtdm::f64_from_bits(fraction | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
+}
+__device__ __forceinline__ double standard_f64(Rng &r) { return (1.0 / 9007199254740992.0) * (double)(next_u64(r) >> 11); }
+
+/* StandardNormal: ziggurat(symmetric), rand 0.5 distributions/mod.rs */
+__device__ double standard_normal(Rng &r) {
+    for (;;) {
+        const unsigned long long bits = next_u64(r);
+        const uint32_t i = (uint32_t)(bits & 0xffull);
+        const double u = rtdm::f64_from_bits((bits >> 12) | 0x4000000000000000ull) - 3.0;
+        const double x = u * ZIG_X[i];
+        const double test_x = x < 0.0 ? -x : x;
+        if (test_x < ZIG_X[i + 1u]) return x;
+        if (i == 0u) {
+            double xx = 1.0, yy = 0.0;
+            while (-2.0 * yy < xx * xx) {
+                const double x_ = open01_f64(r);
+                const double y_ = open01_f64(r);
+                xx = rtdm::log_pos(x_) / RT_ZIG_NORM_R;
+                yy = rtdm::log_pos(y_);
+            }
+            return u < 0.0 ? xx - RT_ZIG_NORM_R : RT_ZIG_NORM_R - xx;
+        }
+        const double z = -x * x / 2.0;
+        const double pdf = z < -700.0 ? 0.0 : rtdm::exp_mid(z);
+        if (ZIG_F[i + 1u] + (ZIG_F[i] - ZIG_F[i + 1u]) * standard_f64(r) < pdf) return x;
+    }
+}
+
+__global__ __launch_bounds__(256) void rng_seed_kernel(uint32_t *states, uint32_t cols, uint32_t rows, uint32_t x0, uint32_t y0, uint32_t y_step) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= cols * rows) return;
+    const uint32_t row = p / cols, col = p - row * cols;
+    const unsigned long long y = y0 + (unsigned long long)row * y_step, x = x0 + col;
+    isaac_seed(states + (size_t)p * RNG_WORDS, y * (2ull << 32) + x); /* main.rs:1119 */
+}
+
+hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t stream) {
+    const uint32_t n = fr.cols * fr.rows;
+    if (n == 0u) return hipSuccess;
+    hipLaunchKernelGGL(rng_seed_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, states, fr.cols, fr.rows, fr.x0, fr.y0, fr.y_step);
+    return hipGetLastError();
+}
+
+/* ---- the kernel ------------------------------------------------------------------------------- */
+
+enum : uint32_t {
+    DP_DONE = 0u,
+    DP_PRIMARY = 1u,     /* cast of the shoot_focus ray                        (main.rs:1150) */
+    DP_NEXT = 2u,        /* cast of the reflected / escape ray of a level      (main.rs:564, 583, 603) */
+    DP_SHADOW = 3u,      /* a shadow ray of get_shade                          (main.rs:435) */
+    DP_REFR_INSIDE = 4u, /* get_refract's first inside cast                    (main.rs:371) */
+    DP_REFR_BOUNCE = 5u  /* a total-internal-reflection bounce                 (main.rs:381) */
+};
+
+struct DFrame {
+    V3 shade;        /* get_shade(&next_hit) */
+    V3 factor;       /* brdf (kinds 0, 1) or (decay, -, -) (kind 2) */
+    uint32_t kind;   /* 0 Diffuse, 1 Reflection, 2 Refraction */
+};
+
+template <int MAXD>
+__global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t total_slots = fr.cols * fr.rows;
+    const uint32_t band_slots = fr.cols << 3;
+    const uint32_t slot = wave * 64u + lane;
+    const bool in_image = slot < total_slots;
+    /* same slot -> pixel mapping as the Whitted kernel: 8-row bands, column-major inside a band */
+    uint32_t out_index = 0u;
+    float clip_x = 0.0f, clip_y = 0.0f;
+    if (in_image) {
+        const uint32_t band = slot / band_slots;
+        const uint32_t r = slot - band * band_slots;
+        const uint32_t rows_left = fr.rows - (band << 3);
+        const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
+        const uint32_t col = r / band_rows;
+        const uint32_t row = (band << 3) + (r - col * band_rows);
+        out_index = row * fr.cols + col;
+        const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+        clip_y = (fr.half_height - (float)y) / fr.height_f; /* main.rs:1134-1135 */
+        clip_x = ((float)x - fr.half_width) / fr.height_f;
+    }
+    const V3 cam_x = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
+    const V3 cam_y = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
+    const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
+    const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
+    const size_t n_pixels = total_slots;
+
+    Rng rng;
+    rng.st = dp.rng_states + (size_t)(in_image ? out_index : 0u) * RNG_WORDS;
+    rng.index = in_image ? rng.st[RNG_INDEX] : 256u;
+
+    uint32_t phase = DP_DONE;
+    uint32_t epoch = 0u;
+    Ray req;
+    req.o = v3(0.0f, 0.0f, 0.0f);
+    req.d = v3(0.0f, 0.0f, 1.0f);
+    req.mode = FACE_FRONT;
+    req.excl = 0u;
+    uint32_t casts = 0u;
+
+    HitGeom h; /* the hit of the current level */
+    h.pos = h.normal = v3(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.prim = h.bf = h.obj = 0u;
+    V3 h_in_dir = v3(0.0f, 0.0f, 0.0f); /* hit.ray.direction */
+    uint32_t h_in_mode = FACE_FRONT;     /* hit.ray.face_direction */
+    V3 sdir = v3(0.0f, 0.0f, 0.0f);     /* scattered_hit.ray.direction */
+    uint32_t kind = 0u;                  /* RayType selected at this level */
+    V3 view_dir_in = v3(0.0f, 0.0f, 0.0f); /* ray direction used as `hit.ray` by the get_shade in progress */
+    uint32_t shade_then = 0u;            /* 0: result is the level's value (return), 1: result is get_shade(next_hit) (descend) */
+    int32_t sp = 0;
+    V3 sum = v3(0.0f, 0.0f, 0.0f), adj_n = v3(0.0f, 0.0f, 0.0f), l_color = v3(0.0f, 0.0f, 0.0f);
+    uint32_t light_i = 0u;
+    float travel = 0.0f;
+    int32_t retry = 0;
+    V3 accum = v3(0.0f, 0.0f, 0.0f);
+    DFrame stack[MAXD];
+
+    /* Camera::shoot_focus for the next epoch of this pixel (main.rs:101-127) */
+    auto start_epoch = [&]() {
+        const V3 direction = normalize(clip_x * cam_x + clip_y * cam_y + cam_t);
+        const float xoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng)); /* Normal::new(0.0, blur as f64) */
+        const float yoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng));
+        req.d = normalize(direction * dp.focus + cam_x * xoffset + cam_y * yoffset);
+        /* center + toward.normalize() * near - (x*xo + y*yo); the first two terms are per-frame (rt_api.hip) */
+        req.o = cam_o - (cam_x * xoffset + cam_y * yoffset);
+        req.mode = FACE_FRONT;
+        req.excl = 0u;
+        sp = 0;
+        phase = DP_PRIMARY;
+    };
+
+    if (in_image && dp.n_epochs > 0u) {
+        if (dp.accum != nullptr) accum = v3(dp.accum[(size_t)out_index * 3u], dp.accum[(size_t)out_index * 3u + 1u], dp.accum[(size_t)out_index * 3u + 2u]);
+        start_epoch();
+    }
+
+    while (__builtin_amdgcn_ballot_w64(phase != DP_DONE) != 0ull) {
+        CastResult cr;
+        cr.prim = -1;
+        cr.t = 0.0f;
+        cr.bf = 0u;
+        cr.a0 = cr.a1 = cr.a2 = 0.0f;
+        if (phase != DP_DONE) {
+            cr = cast<false>(sc, nullptr, req);
+            casts += 1u;
+        }
+        if (phase == DP_DONE) continue;
+
+        enum { GO_LEVEL, GO_START_SHADE, GO_NEXT_LIGHT, GO_SHADE_DONE, GO_TRY_EXIT, GO_RETURN } go = GO_RETURN;
+        V3 value = v3(0.0f, 0.0f, 0.0f);
+        HitGeom ih = h; /* inside hit of get_refract, live within this step only */
+        V3 i_in_dir = req.d;
+        uint32_t i_in_mode = req.mode;
+
+        if (phase == DP_PRIMARY) {
+            if (cr.prim < 0) {
+                value = v3(0.0f, 0.0f, 0.0f); /* main.rs:1154 */
+                go = GO_RETURN;
+            } else {
+                h = finish_hit(sc, req, cr, false);
+                h_in_dir = req.d;
+                h_in_mode = req.mode;
+                go = GO_LEVEL;
+            }
+        } else if (phase == DP_NEXT) {
+            if (cr.prim < 0) {
+                if (kind == 2u) { /* main.rs:606-608 */
+                    value = v3(0.0f, 0.0f, 0.0f);
+                    go = GO_RETURN;
+                } else { /* get_shade(&scattered_hit): the same hit, seen along the scattered direction (main.rs:573, 592) */
+                    view_dir_in = sdir;
+                    shade_then = 0u;
+                    go = GO_START_SHADE;
+                }
+            } else {
+                /* brdf of the CURRENT level, before `h` moves on to the next hit (main.rs:566-570, 585-589) */
+                DFrame f;
+                f.kind = kind;
+                f.shade = v3(0.0f, 0.0f, 0.0f);
+                if (kind == 2u) {
+                    f.factor = v3(rtdm::powf(sc.materials[h.obj].opaque_decay, travel), 0.0f, 0.0f); /* main.rs:605 */
+                } else {
+                    const Mat m = material_approx(sc.materials[h.obj], h.u, h.v);
+                    const V3 view = -h_in_dir;
+                    f.factor = kind == 0u ? get_diffuse(m, h.normal, req.d) : get_specular(m, h.normal, view, req.d);
+                }
+                stack[sp] = f;
+                h = finish_hit(sc, req, cr, false);
+                h_in_dir = req.d;
+                h_in_mode = req.mode;
+                view_dir_in = req.d;
+                shade_then = 1u;
+                go = GO_START_SHADE;
+            }
+        } else if (phase == DP_SHADOW) {
+            const rt_light &L = sc.lights[light_i];
+            bool lit = true;
+            if (cr.prim >= 0) {
+                const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
+                if (has_origin) {
+                    const V3 occ = req.o + req.d * cr.t;
+                    if (distance(h.pos, occ) < distance(h.pos, v3(L.origin[0], L.origin[1], L.origin[2]))) lit = false;
+                } else {
+                    lit = false;
+                }
+            }
+            if (lit) {
+                const Mat m = material_approx(sc.materials[h.obj], h.u, h.v);
+                const V3 light_direction = req.d;
+                const V3 diffuse = get_diffuse(m, adj_n, light_direction) * l_color;
+                const V3 specular = get_specular(m, adj_n, -view_dir_in, light_direction) * l_color;
+                sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
+            }
+            light_i += 1u;
+            go = GO_NEXT_LIGHT;
+        } else { /* DP_REFR_INSIDE / DP_REFR_BOUNCE */
+            if (cr.prim < 0) {
+                value = v3(0.0f, 0.0f, 0.0f); /* Refraction::Infinite -> black (main.rs:610) */
+                go = GO_RETURN;
+            } else {
+                ih = finish_hit(sc, req, cr, false);
+                i_in_dir = req.d;
+                i_in_mode = req.mode;
+                if (phase == DP_REFR_INSIDE) {
+                    travel = distance(ih.pos, h.pos);
+                    retry = 0;
+                } else {
+                    travel += distance(req.o, ih.pos);
+                    retry += 1;
+                }
+                go = GO_TRY_EXIT;
+            }
+        }
+
+        for (;;) {
+            if (go == GO_LEVEL) {
+                /* distributed_ray_trace(state, &h), depth = max_depth - sp */
+                const int32_t depth = fr.max_depth - sp;
+                if (depth <= 0) { /* main.rs:524-527 */
+                    view_dir_in = h_in_dir;
+                    shade_then = 0u;
+                    go = GO_START_SHADE;
+                    continue;
+                }
+                const rt_material &rm = sc.materials[h.obj];
+                /* weighted_select (main.rs:652-666) */
+                const float w0 = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                const float w1 = rm.shiness * (1.0f - rm.transparency);
+                const float w2 = rm.transparency;
+                float wsum = 0.0f;
+                wsum = wsum + w0;
+                wsum = wsum + w1;
+                wsum = wsum + w2;
+                const float rsel = gen_range_f32(rng, 0.0f, wsum);
+                float acc = 0.0f;
+                acc += w0;
+                kind = 2u;
+                if (rsel < acc) kind = 0u;
+                else {
+                    acc += w1;
+                    if (rsel < acc) kind = 1u;
+                }
+                /* scatter_hit (main.rs:539-554) */
+                const float exponent = kind == 0u ? 1.0f : rm.smoothness;
+                const V3 lobe = kind == 0u ? -h.normal : h_in_dir;
+                const float phi = rtdm::acosf(rtdm::powf(1.0f - gen_range_f32(rng, 0.0f, 1.0f), exponent));
+                const float theta = gen_range_f32(rng, -RT_F_PI, RT_F_PI);
+                const float sphi = rtdm::sinf(phi), cphi = rtdm::cosf(phi);
+                sdir = adjust_normal(v3(sphi * rtdm::cosf(theta), sphi * rtdm::sinf(theta), cphi), normalize(lobe));
+                const float cosine = -dot(h.normal, sdir);
+                if (cosine <= 0.0f) { /* main.rs:560, 579, 598 */
+                    value = v3(0.0f, 0.0f, 0.0f);
+                    go = GO_RETURN;
+                    continue;
+                }
+                if (kind != 2u) {
+                    /* get_reflect(&scattered_hit) (main.rs:328-341) */
+                    req.o = h.pos;
+                    req.d = reflect_dir(h.normal, sdir);
+                    req.mode = h_in_mode;
+                    req.excl = pack_excl(h.prim, h.bf ? FACE_FRONT : FACE_BACK);
+                    phase = DP_NEXT;
+                    break;
+                }
+                /* get_refract(&scattered_hit, 100.0) (main.rs:343-405) */
+                V3 refract_in;
+                if (refract_dir(h.normal, sdir, rm.refraction_index, &refract_in)) {
+                    req.o = h.pos;
+                    req.d = normalize(refract_in);
+                    req.mode = FACE_BACK;
+                    req.excl = pack_excl(h.prim, FACE_FRONT);
+                    phase = DP_REFR_INSIDE;
+                    break;
+                }
+                value = v3(0.0f, 0.0f, 0.0f); /* Trapped */
+                go = GO_RETURN;
+            } else if (go == GO_TRY_EXIT) {
+                const rt_material &rm = sc.materials[h.obj];
+                V3 out_dir;
+                const bool have_out = refract_dir(ih.normal, i_in_dir, 1.0f / rm.refraction_index, &out_dir);
+                if (!have_out && travel <= 100.0f && retry < 10) {
+                    req.o = ih.pos;
+                    req.d = reflect_dir(ih.normal, i_in_dir);
+                    req.mode = i_in_mode;
+                    req.excl = pack_excl(ih.prim, ih.bf ? FACE_FRONT : FACE_BACK);
+                    phase = DP_REFR_BOUNCE;
+                    break;
+                }
+                if (!have_out) { /* Trapped */
+                    value = v3(0.0f, 0.0f, 0.0f);
+                    go = GO_RETURN;
+                    continue;
+                }
+                req.o = ih.pos; /* escape ray, main.rs:393-401 */
+                req.d = normalize(out_dir);
+                req.mode = FACE_FRONT;
+                req.excl = pack_excl(ih.prim, FACE_BACK);
+                phase = DP_NEXT;
+                break;
+            } else if (go == GO_START_SHADE) {
+                /* get_shade(&h') where h' = h with ray.direction = view_dir_in (main.rs:407-412) */
+                const Mat m = material_approx(sc.materials[h.obj], h.u, h.v);
+                adj_n = adjust_normal(m.normal, h.normal);
+                sum = v3(0.0f, 0.0f, 0.0f);
+                light_i = 0u;
+                go = GO_NEXT_LIGHT;
+            } else if (go == GO_NEXT_LIGHT) {
+                bool issued = false;
+                while (light_i < sc.n_lights) {
+                    DirLight dl;
+                    if (approximate_into_directional(sc.lights[light_i], h.pos, &dl)) {
+                        const float cosine = -dot(dl.direction, adj_n);
+                        if (!(cosine <= 0.0f)) {
+                            req.o = h.pos;
+                            req.d = -dl.direction;
+                            req.mode = FACE_BACK;
+                            req.excl = pack_excl(h.prim, FACE_BACK);
+                            l_color = dl.color;
+                            phase = DP_SHADOW;
+                            issued = true;
+                            break;
+                        }
+                    }
+                    light_i += 1u;
+                }
+                if (issued) break;
+                go = GO_SHADE_DONE;
+            } else if (go == GO_SHADE_DONE) {
+                if (shade_then == 1u) { /* that was get_shade(&next_hit): keep it and descend (main.rs:565, 584, 604) */
+                    stack[sp].shade = sum;
+                    sp += 1;
+                    go = GO_LEVEL;
+                } else {
+                    value = sum;
+                    go = GO_RETURN;
+                }
+            } else { /* GO_RETURN */
+                if (sp > 0) {
+                    const DFrame f = stack[sp - 1];
+                    if (f.kind == 2u) {
+                        value = (value + f.shade) * f.factor.x; /* main.rs:605 */
+                    } else {
+                        const V3 s = value * f.factor;           /* main.rs:566, 585 */
+                        value = f.shade + (s - f.shade) * 0.5f;  /* palette Mix::mix(&s, 0.5), main.rs:571, 590 */
+                    }
+                    sp -= 1;
+                    continue;
+                }
+                /* the sample of this (pixel, epoch): filter (main.rs:1157-1160) and accumulate (main.rs:1165) */
+                const bool ok = rtdm::is_normal(value.x) && rtdm::is_normal(value.y) && rtdm::is_normal(value.z);
+                if (dp.samples != nullptr) {
+                    float *o = dp.samples + ((size_t)epoch * n_pixels + out_index) * 3u;
+                    o[0] = value.x; o[1] = value.y; o[2] = value.z;
+                }
+                if (dp.valid != nullptr) dp.valid[(size_t)epoch * n_pixels + out_index] = ok ? 1 : 0;
+                if (ok) accum = accum + value;
+                epoch += 1u;
+                if (epoch < dp.n_epochs) {
+                    start_epoch();
+                } else {
+                    phase = DP_DONE;
+                }
+                break;
+            }
+        }
+    }
+
+    if (in_image) {
+        rng.st[RNG_INDEX] = rng.index;
+        if (dp.accum != nullptr && dp.n_epochs > 0u) {
+            float *o = dp.accum + (size_t)out_index * 3u;
+            o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
+        }
+    }
+    if (dp.ray_count != nullptr) {
+        uint32_t c = casts;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0u && c != 0u) atomicAdd(dp.ray_count, (unsigned long long)c);
+    }
+}
+
+hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream) {
+    const uint32_t total = fr.cols * fr.rows;
+    const uint32_t waves = (total + 63u) / 64u;
+    if (waves == 0u) return hipSuccess;
+    if (fr.max_depth <= 8) {
+        hipLaunchKernelGGL((distributed_kernel<9>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    } else {
+        hipLaunchKernelGGL((distributed_kernel<RT_MAX_DEPTH + 1>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    }
+    return hipGetLastError();
+}
+
+} /* namespace rt */

@@ -61,6 +61,7 @@ struct KernelFrame {
     float cam_x[3];          /* tan(fovy/2) * right */
     float cam_y[3];          /* tan(fovy/2) * up' */
     float cam_toward[3];     /* normalize(toward) */
+    float cam_origin_focus[3]; /* center + normalize(normalize(toward)) * near: shoot_focus normalises twice (main.rs:119) */
 };
 
 /* device-side queues of one launch */
@@ -80,6 +81,20 @@ uint32_t cont_record_dwords(int32_t max_depth);
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                           const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
+
+/* distributed pass (rt_distributed.hip) */
+struct DistParams {
+    uint32_t *rng_states;          /* RT_RNG_STATE_WORDS u32 per tile pixel */
+    uint32_t n_epochs;
+    float focus, blur;             /* main.rs:1147-1148 */
+    float *accum;                  /* pixels*3, += every surviving sample; may be null */
+    float *samples;                /* n_epochs*pixels*3 raw samples; may be null */
+    unsigned char *valid;          /* n_epochs*pixels filter flags; may be null */
+    unsigned long long *ray_count; /* may be null */
+};
+#define RT_RNG_STATE_WORDS 516u
+hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t stream);
+hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream);
 
 /* diagnostics: evaluate rt_detmath on the device (op codes = rt_math_op) */
 hipError_t launch_math_eval(int op, const float *d_x, const float *d_y, float *d_out, size_t n, hipStream_t stream);

@@ -188,6 +188,35 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
 int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame,
                            float *h_rgb, unsigned long long *h_ray_count);
 
+/* ---- distributed (stochastic / depth-of-field) pass ----------------------------
+
+ * Replaces the par_iter_mut closure at src/main.rs:1131-1156 and the per-pixel RNG construction at
+ * main.rs:1117-1127.  rt_rng is the device-resident array of per-pixel IsaacRng states of one tile
+ * (rand 0.5 IsaacRng::new_from_u64(y * 2^33 + x); 516 u32 per pixel: mem[256], a, b, c, results[256],
+ * index).  It is mutable and exclusive to one render call at a time (the reference hands each pixel
+ * `&mut` access, main.rs:1131); the random stream continues from call to call. */
+typedef struct rt_rng rt_rng;
+
+int rt_rng_state_words(void);
+int rt_rng_create(const rt_frame *frame, rt_rng **out_rng);
+int rt_rng_destroy(rt_rng *rng);
+/* Copy the states to the host (rt_frame_pixels * rt_rng_state_words u32) — for tests. */
+int rt_rng_download(const rt_rng *rng, uint32_t *h_states);
+
+/* n_epochs passes over the tile.  Per pixel and epoch: shoot_focus(focus, blur) (main.rs:1144-1149,
+ * reference literals 3.0 / 0.04) -> cast -> distributed_ray_trace(depth = max_depth).
+ *   d_accum    device, pixels*3 floats or NULL: every sample that passes the filter of main.rs:1157-1160
+ *              (all three channels is_normal) is ADDED, in epoch order (img[at] = img[at] + photon,
+ *              main.rs:1165).  Calling with n_epochs = 1 and running post_process in between reproduces
+ *              the reference's per-epoch renormalisation (main.rs:1171).
+ *   d_samples  device, n_epochs*pixels*3 floats or NULL: the raw sample of every (epoch, pixel).
+ *   d_valid    device, n_epochs*pixels bytes or NULL: 1 where the sample passed the filter.
+ *   d_ray_count as in rt_render_whitted.
+ * At least one of d_accum / d_samples must be given. */
+int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
+                          rt_rng *rng, uint32_t n_epochs, float *d_accum, float *d_samples, unsigned char *d_valid,
+                          unsigned long long *d_ray_count, void *hip_stream);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 
 /* Kernel variant used by the render entry points of this process (bit field):

@@ -67,6 +67,15 @@ float orc_post_process(float *rgb, size_t n_pixels, int luma_mode);
 void orc_luma_row(int luma_mode, float *row3);
 void orc_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out);
 
+size_t orc_rng_state_words(void);
+void orc_rng_init(const rt_frame *frame, uint32_t *states);
+void orc_rng_draw_u32(uint32_t *state, uint32_t *out, size_t n);
+void orc_rng_draw_normal(uint32_t *state, double mean, double std_dev, double *out, size_t n);
+void orc_rng_draw_range_f32(uint32_t *state, float low, float high, float *out, size_t n);
+void orc_render_distributed(const rt_scene_desc *scene, const rt_camera *camera, const rt_frame *frame, float focus,
+                            float blur, uint32_t *rng_states, uint32_t n_epochs, float *samples, uint8_t *valid,
+                            uint64_t *out_casts, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

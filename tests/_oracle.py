@@ -114,3 +114,41 @@ def encode_srgb8(img: np.ndarray, kind: str = "detmath") -> np.ndarray:
     out = np.empty(img.shape, dtype=np.uint8)
     lib(kind).orc_encode_srgb8(img.ctypes.data, img.size, out.ctypes.data)
     return out
+
+
+def _dist_lib(kind="detmath"):
+    l = lib(kind)
+    if not getattr(l, "_dist_ready", False):
+        l.orc_rng_state_words.restype = C.c_size_t
+        l.orc_rng_init.argtypes = [C.POINTER(Frame), C.c_void_p]
+        l.orc_rng_init.restype = None
+        l.orc_rng_draw_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.orc_rng_draw_u32.restype = None
+        l.orc_rng_draw_normal.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_size_t]
+        l.orc_rng_draw_normal.restype = None
+        l.orc_rng_draw_range_f32.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_size_t]
+        l.orc_rng_draw_range_f32.restype = None
+        l.orc_render_distributed.argtypes = [C.POINTER(SceneDesc), C.POINTER(Camera), C.POINTER(Frame), C.c_float, C.c_float,
+                                             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        l.orc_render_distributed.restype = None
+        l._dist_ready = True
+    return l
+
+
+def rng_init(frame: Frame, kind="detmath") -> np.ndarray:
+    l = _dist_lib(kind)
+    words = l.orc_rng_state_words()
+    st = np.zeros((frame.rows * frame.cols, words), dtype=np.uint32)
+    l.orc_rng_init(C.byref(frame), st.ctypes.data)
+    return st
+
+
+def render_distributed(desc, camera, frame, rng_states, n_epochs, focus=3.0, blur=0.04, threads=0, kind="detmath"):
+    """Returns (samples[n_epochs, rows, cols, 3] f32, valid[n_epochs, rows, cols] u8, casts); rng_states advance in place."""
+    l = _dist_lib(kind)
+    samples = np.empty((n_epochs, frame.rows, frame.cols, 3), dtype=np.float32)
+    valid = np.empty((n_epochs, frame.rows, frame.cols), dtype=np.uint8)
+    casts = C.c_uint64(0)
+    l.orc_render_distributed(C.byref(desc), C.byref(camera), C.byref(frame), focus, blur, rng_states.ctypes.data, n_epochs,
+                             samples.ctypes.data, valid.ctypes.data, C.byref(casts), threads)
+    return samples, valid, int(casts.value)
