@@ -44,7 +44,8 @@ def test_argument_validation_returns_status():
     assert lib.rt_frame_pixels(C.byref(bad)) == 0
     good = rt.Frame.rows_of_rank(1920, 1080, 8, 3, 8)
     assert lib.rt_frame_rows(C.byref(good)) == 135 and lib.rt_frame_pixels(C.byref(good)) == 135 * 1920
-    assert lib.rt_set_variant(7) == -1
+    assert lib.rt_set_variant(99) == -1 and lib.rt_set_eviction(64, 0) == -1
+    assert lib.rt_rng_create(None, None) == -1 and lib.rt_render_distributed(None, None, None, 3.0, 0.04, None, 1, None, None, None, None, None) == -1
 
 
 def test_scene_validation():
