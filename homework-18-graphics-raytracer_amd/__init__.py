@@ -82,14 +82,16 @@ class World:
     """Host-side scene under construction; src/main.rs:130-178."""
 
     def __init__(self):
-        self._h = _capi.host_lib().rt_world_new()
+        lib = _capi.host_lib()
+        self._free = lib.rt_world_free  # bound now: module globals may be gone at interpreter shutdown
+        self._h = lib.rt_world_new()
         if not self._h:
             raise MemoryError("rt_world_new failed")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _capi.host_lib().rt_world_free(h)
+            self._free(h)
 
     def push_object(self, material: Material) -> ObjectProxy:
         idx = _capi.check_host(_capi.host_lib().rt_world_push_object(self._h, C.byref(material)))
