@@ -112,6 +112,80 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
     return best;
 }
 
+/* ---- World::cast with the hand-scheduled triangle loop (rt_cast_asm.h, tools/gen_cast_asm.py) ----------
+ * The asm block does main.rs:183-233 for all triangles and returns, per lane, the nearest accepted travel
+ * distance and triangle index (best_t = NaN / best_prim = -1 while None: `nearest_t < t` is false for NaN,
+ * which is exactly the reference's Option::None case).  The signed areas and the backface flag of the winner
+ * are pure functions of (ray, triangle, t) and are re-evaluated once after the loop with the same operations;
+ * the sphere loop (main.rs:264-324) stays in C++. */
+#include "rt_cast_asm.h"
+
+__device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
+    const uint32_t nt = sc.n_triangles;
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+    /* lane predicates as wave-wide masks in SGPR pairs */
+    const unsigned long long keep_back = __builtin_amdgcn_ballot_w64(ray.mode != FACE_FRONT);  /* backfaces survive culling */
+    const unsigned long long keep_front = __builtin_amdgcn_ballot_w64(ray.mode != FACE_BACK);
+    const unsigned long long ex_if_back = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_FRONT);  /* Back or Both */
+    const unsigned long long ex_if_front = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_BACK);  /* Front or Both */
+    const uint32_t exid = (ex_some && ex_prim < nt) ? ex_prim : 0xffffffffu;
+    float best_t = rtdm::quiet_nan();
+    int32_t best_prim = -1;
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12;
+    const unsigned long long ptr = (unsigned long long)(uintptr_t)sc.tris;
+    asm volatile(RT_CAST_ASM_TEXT
+                 : "+v"(best_t), "+v"(best_prim), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6),
+                   "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12)
+                 : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(keep_back),
+                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(nt)
+                 : RT_CAST_ASM_CLOBBERS);
+
+    CastResult best;
+    best.prim = best_prim;
+    best.t = best_t;
+    best.bf = 0u;
+    best.a0 = best.a1 = best.a2 = 0.0f;
+    bool have = best_prim >= 0;
+    if (have) { /* the winner's backface flag and signed areas (main.rs:184, 218-222), same operations as in the loop */
+        const DevTri &T = sc.tris[best_prim];
+        const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+        best.bf = dot(n, ray.d) > 0.0f ? 1u : 0u;
+        const V3 p = ray.o + ray.d * best_t;
+        best.a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
+        best.a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
+        best.a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
+    }
+    const uint32_t ns = sc.n_spheres;
+    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
+        const DevSphere &S = sc.spheres[i];
+        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
+        const V3 disp = c - ray.o;
+        const float lsd = magnitude(cross(disp, ray.d));
+        if (lsd > S.radius) continue;
+        const float tc = dot(ray.d, disp);
+        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
+        float t;
+        bool bf;
+        if (ray.mode == FACE_FRONT) { t = tc - k; bf = false; }
+        else if (ray.mode == FACE_BACK) { t = tc + k; bf = true; }
+        else if (tc < k) { t = tc + k; bf = true; }
+        else { t = tc - k; bf = false; }
+        if (t <= 0.0f) continue;
+        if (ex_some && ex_prim == nt + i) {
+            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+            if (criteria) continue;
+        }
+        if (have && best.t < t) continue;
+        have = true;
+        best.t = t;
+        best.prim = (int32_t)(nt + i);
+        best.bf = bf ? 1u : 0u;
+    }
+    return best;
+}
+
 /* What the state machine keeps of a Hit (main.rs:139-147). */
 struct HitGeom {
     V3 pos, normal;

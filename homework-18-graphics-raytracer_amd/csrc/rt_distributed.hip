@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
         if (phase != DP_DONE) {
-            cr = cast<false>(sc, nullptr, req);
+            cr = cast_asm(sc, req);
             casts += 1u;
         }
         if (phase == DP_DONE) continue;

@@ -577,8 +577,10 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req)
                          : cast_outlined(sc.tris, sc.n_triangles, sc.spheres, sc.n_spheres, req.o.x, req.o.y, req.o.z, req.d.x, req.d.y,
                                          req.d.z, req.mode, req.excl);
-#else
+#elif defined(RT_CAST_COMPILER) /* the compiler-generated loop (round-1 v1..v3) */
             cr = cast<USE_LDS>(sc, lds_tris, req);
+#else
+            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_asm(sc, req);
 #endif
             casts += 1u;
         }

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Emit csrc/rt_cast_asm.h: the hand-scheduled gfx950 triangle loop of World::cast (main.rs:183-262).
+
+The loop body is written once below, in terms of symbolic register names, and instantiated for the two SGPR
+buffers (A/B) that let triangle i+1 be fetched while triangle i is tested.  Everything about the arithmetic is
+fixed by parity: IEEE binary32 mul/add/sub in the reference's order, the compiler's own correctly rounded
+division sequence (v_div_scale / v_rcp / fma refinement / v_div_fmas / v_div_fixup), literal NaN behaviour of
+the comparisons.  What is hand-made is the control and data flow around it:
+
+  * one 112-byte scalar fetch per triangle (s_load_dwordx16 + x8 + x4) into a buffer of 28 SGPRs, issued one
+    triangle ahead; the other buffer is being tested meanwhile;
+  * lane predicates live in SGPR pairs and are combined with s_and/s_andn2/s_or; EXEC is never narrowed for the
+    arithmetic, so there is no save/restore nesting — three wave-level exits (after culling/exclusion, after
+    t <= 0, after inside+nearest) branch on SCC straight to the next triangle;
+  * the accept is the only EXEC switch: five instructions for the lanes that found a nearer hit.
+
+Hazards handled by construction (gfx9 family): >= 4 instructions between the VCC-writing v_div_scale and
+v_div_fmas; s_nop after v_rcp_f32 before its consumer (trans-use hazard on gfx940+); VALU-written masks are
+only consumed by SALU (interlocked) and branches use SCC, never VCCZ/EXECZ.
+
+    python tools/gen_cast_asm.py > homework-18-graphics-raytracer_amd/csrc/rt_cast_asm.h
+"""
+
+# ---- operand map of the asm statement (see cast_asm() in rt_cast.h) ----
+OUT = {"best_t": 0, "best_prim": 1}
+TEMPS = {f"r{k}": 2 + k for k in range(13)}
+IN = {"ox": 15, "oy": 16, "oz": 17, "dx": 18, "dy": 19, "dz": 20, "exid": 21, "keep_back": 22, "keep_front": 23,
+      "ex_if_back": 24, "ex_if_front": 25, "ptr": 26, "n": 27}
+
+# fixed scalar registers (all in the clobber list)
+# (s32/s33 are the ABI stack/frame pointers and s100/s101 are reserved by the compiler: stay inside s34..s99)
+S_PTR = "s[34:35]"
+S_PTR_LO, S_PTR_HI = "s34", "s35"
+S_I, S_N = "s36", "s37"
+S_ALIVE, S_T1, S_T2 = "s[38:39]", "s[96:97]", "s[98:99]"
+S_EXSAVE = S_T2
+
+BUF = {
+    "A": {"x16": "s[40:55]", "x8": "s[56:63]", "x4": "s[64:67]", "base": 40},
+    "B": {"x16": "s[68:83]", "x8": "s[84:91]", "x4": "s[92:95]", "base": 68},
+}
+
+
+def regs(buf):
+    b = BUF[buf]["base"]
+    names = ["nx", "ny", "nz", "d", "v0x", "v0y", "v0z", "obj", "v1x", "v1y", "v1z", "area", "v2x", "v2y", "v2z", "pad0",
+             "e0x", "e0y", "e0z", "pad1", "e1x", "e1y", "e1z", "pad2", "e2x", "e2y", "e2z", "pad3"]
+    return {n: f"s{b + k}" for k, n in enumerate(names)}
+
+
+def op(name):
+    if name in OUT:
+        return f"%{OUT[name]}"
+    if name in TEMPS:
+        return f"%{TEMPS[name]}"
+    return f"%{IN[name]}"
+
+
+def loads(buf, offset):
+    b = BUF[buf]
+    return [
+        f"s_load_dwordx16 {b['x16']}, {S_PTR}, {hex(offset)}",
+        f"s_load_dwordx8 {b['x8']}, {S_PTR}, {hex(offset + 0x40)}",
+        f"s_load_dwordx4 {b['x4']}, {S_PTR}, {hex(offset + 0x60)}",
+    ]
+
+
+def dot_sv(dst, tmp, s3, v3):
+    """dst = (s.x*v.x + s.y*v.y) + s.z*v.z   (cgmath dot, left to right)"""
+    return [
+        f"v_mul_f32 {dst}, {s3[0]}, {v3[0]}",
+        f"v_mul_f32 {tmp}, {s3[1]}, {v3[1]}",
+        f"v_add_f32 {dst}, {dst}, {tmp}",
+        f"v_mul_f32 {tmp}, {s3[2]}, {v3[2]}",
+        f"v_add_f32 {dst}, {dst}, {tmp}",
+    ]
+
+
+def area(dst, e, vtx, p, w, c, tmp, n):
+    """dst = dot(cross(e, p - vtx), n)   (main.rs:219-221)"""
+    out = [f"v_subrev_f32 {w[k]}, {vtx[k]}, {p[k]}" for k in range(3)]  # w = p - vtx
+    out += [
+        f"v_mul_f32 {c[0]}, {e[1]}, {w[2]}", f"v_mul_f32 {tmp}, {e[2]}, {w[1]}", f"v_sub_f32 {c[0]}, {c[0]}, {tmp}",
+        f"v_mul_f32 {c[1]}, {e[2]}, {w[0]}", f"v_mul_f32 {tmp}, {e[0]}, {w[2]}", f"v_sub_f32 {c[1]}, {c[1]}, {tmp}",
+        f"v_mul_f32 {c[2]}, {e[0]}, {w[1]}", f"v_mul_f32 {tmp}, {e[1]}, {w[0]}", f"v_sub_f32 {c[2]}, {c[2]}, {tmp}",
+        f"v_mul_f32 {c[0]}, {n[0]}, {c[0]}", f"v_mul_f32 {c[1]}, {n[1]}, {c[1]}", f"v_add_f32 {c[0]}, {c[0]}, {c[1]}",
+        f"v_mul_f32 {c[2]}, {n[2]}, {c[2]}", f"v_add_f32 {dst}, {c[0]}, {c[2]}",
+    ]
+    return out
+
+
+def test(buf, label_next):
+    T = regs(buf)
+    n = (T["nx"], T["ny"], T["nz"])
+    d = (op("dx"), op("dy"), op("dz"))
+    o = (op("ox"), op("oy"), op("oz"))
+    r = [op(f"r{k}") for k in range(13)]
+    nd, num = r[11], r[12]  # num becomes t
+    t = num
+    L = []
+    # nd = n . d ; bf = nd > 0
+    L += dot_sv(nd, r[9], n, d)
+    L += [f"v_cmp_lt_f32 vcc, 0, {nd}"]
+    # alive = bf ? keep_back : keep_front          (culling, main.rs:185-188)
+    L += [f"s_and_b64 {S_ALIVE}, vcc, {op('keep_back')}", f"s_andn2_b64 {S_T1}, {op('keep_front')}, vcc", f"s_or_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}"]
+    # exclusion: same primitive and (bf ? ex_if_back : ex_if_front)   (main.rs:190-200)
+    L += [f"v_cmp_eq_u32_e64 {S_T2}, {S_I}, {op('exid')}",
+          f"s_and_b64 {S_T1}, vcc, {op('ex_if_back')}", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
+          f"s_andn2_b64 {S_T1}, {op('ex_if_front')}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
+          f"s_and_b64 {S_ALIVE}, {S_ALIVE}, exec", f"s_cbranch_scc0 {label_next}"]
+    # num = d - n . o                              (main.rs:203-204)
+    L += dot_sv(r[9], r[10], n, o)
+    L += [f"v_sub_f32 {num}, {T['d']}, {r[9]}"]
+    # t = num / nd, correctly rounded (the sequence hipcc emits for an IEEE f32 divide)
+    q0, rc, e, q1, q = r[0], r[1], r[2], r[3], r[4]
+    L += [f"v_div_scale_f32 {q0}, {S_T1}, {nd}, {nd}, {num}",
+          f"v_rcp_f32 {rc}, {q0}",
+          "s_nop 0",
+          f"v_fma_f32 {e}, -{q0}, {rc}, 1.0",
+          f"v_fmac_f32 {rc}, {e}, {rc}",
+          f"v_div_scale_f32 {q1}, vcc, {num}, {nd}, {num}",
+          f"v_mul_f32 {q}, {q1}, {rc}",
+          f"v_fma_f32 {e}, -{q0}, {q}, {q1}",
+          f"v_fmac_f32 {q}, {e}, {rc}",
+          f"v_fma_f32 {q0}, -{q0}, {q}, {q1}",
+          f"v_div_fmas_f32 {q0}, {q0}, {rc}, {q}",
+          f"v_div_fixup_f32 {t}, {q0}, {nd}, {num}"]
+    # alive &= !(t <= 0)   (NaN passes, main.rs:205)
+    L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    # p = o + d * t
+    p = (r[0], r[1], r[2])
+    for k in range(3):
+        L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
+    w = (r[3], r[4], r[5])
+    e0 = (T["e0x"], T["e0y"], T["e0z"]); e1 = (T["e1x"], T["e1y"], T["e1z"]); e2 = (T["e2x"], T["e2y"], T["e2z"])
+    v0 = (T["v0x"], T["v0y"], T["v0z"]); v1 = (T["v1x"], T["v1y"], T["v1z"]); v2 = (T["v2x"], T["v2y"], T["v2z"])
+    L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
+    L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
+    L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
+    # inside: none of the areas < 0 (NaN passes, main.rs:224) ; nearest: !(best_t < t), best_t = NaN while None
+    L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc",
+          f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    # accept for the lanes in alive
+    L += [f"s_mov_b64 {S_EXSAVE}, exec", f"s_mov_b64 exec, {S_ALIVE}",
+          f"v_mov_b32 {op('best_t')}, {t}", f"v_mov_b32 {op('best_prim')}, {S_I}",
+          f"s_mov_b64 exec, {S_EXSAVE}"]
+    return L
+
+
+def main():
+    L = []
+    L += [f"s_mov_b64 {S_PTR}, {op('ptr')}", f"s_mov_b32 {S_N}, {op('n')}", f"s_mov_b32 {S_I}, 0",
+          f"s_cmp_eq_u32 {S_N}, 0", "s_cbranch_scc1 .Lcast_done_%="]
+    L += loads("A", 0)
+    L += [".Lcast_loop_%=:", "s_waitcnt lgkmcnt(0)"]
+    L += loads("B", 0x80)
+    L += test("A", ".Lcast_nextA_%=")
+    L += [".Lcast_nextA_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_ge_u32 {S_I}, {S_N}", "s_cbranch_scc1 .Lcast_done_%=",
+          "s_waitcnt lgkmcnt(0)", f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 0x100", f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0"]
+    L += loads("A", 0)
+    L += test("B", ".Lcast_nextB_%=")
+    L += [".Lcast_nextB_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_lt_u32 {S_I}, {S_N}", "s_cbranch_scc1 .Lcast_loop_%=",
+          ".Lcast_done_%=:", "s_waitcnt lgkmcnt(0)"]
+
+    clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"]
+    print("/* GENERATED by tools/gen_cast_asm.py — do not edit; edit the generator. */")
+    print("#ifndef RT_CAST_ASM_H")
+    print("#define RT_CAST_ASM_H")
+    print("#define RT_CAST_ASM_TEXT \\")
+    for line in L:
+        print(f'    "{line}\\n\\t" \\')
+    print('    ""')
+    print("#define RT_CAST_ASM_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers))
+    print(f"#define RT_CAST_ASM_INSTRUCTIONS {len([l for l in L if not l.endswith(':')])}")
+    print("#endif")
+
+
+if __name__ == "__main__":
+    main()
