@@ -367,6 +367,16 @@ RT_HD int32_t f32_as_i32(float x) {
     return (int32_t)x;
 }
 
+#ifdef RT_DIAG_FAKE_MATH /* timing experiment only: results are WRONG; measures what the transcendentals cost */
+namespace fake {
+RT_HD float sinf(float x) { return x * 0.5f; }
+RT_HD float cosf(float x) { return 1.0f - x * 0.25f; }
+RT_HD float acosf(float x) { return 1.5f - x; }
+RT_HD float atan2f(float y, float x) { return y + x; }
+RT_HD float powf(float x, float y) { return x * 0.5f + y * 1e-6f; }
+} /* namespace fake */
+#endif
+
 } /* namespace rtdm */
 
 #endif /* RT_DETMATH_H */

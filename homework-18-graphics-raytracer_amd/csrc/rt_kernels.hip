@@ -407,6 +407,8 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 #ifdef RT_DIAG_TIMELINE /* diagnostic build only: wave start/end on the 100 MHz constant clock, iterations, HW id */
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long diag_cast_cycles = 0ull;
 #endif
     const uint32_t total_slots = fr.cols * fr.rows;
     const uint32_t band_slots = fr.cols << 3;
@@ -568,6 +570,9 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         cr.t = 0.0f;
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
+#ifdef RT_DIAG_TIMELINE
+        const unsigned long long diag_ca = __builtin_amdgcn_s_memtime();
+#endif
         if (phase != PH_DONE) {
 #ifdef RT_CAST_PIPELINED /* experiment: compiler-generated SGPR double buffering; slower than the plain loop (profiles/README) */
             cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_pipelined(sc, req);
@@ -584,6 +589,9 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
 #endif
             casts += 1u;
         }
+#ifdef RT_DIAG_TIMELINE
+        diag_cast_cycles += __builtin_amdgcn_s_memtime() - diag_ca;
+#endif
 
         /* ---- advance this lane until it needs another cast or finishes ---- */
         if (phase != PH_DONE) {
@@ -838,7 +846,8 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         rec[0] = diag_t0;
         rec[1] = diag_t1;
         rec[2] = iteration;
-        rec[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); /* HW_REG_HW_ID */
+        rec[2] = (unsigned long long)iteration | ((__builtin_amdgcn_s_memtime() - diag_c0) << 16); /* iterations | wave cycles */
+        rec[3] = diag_cast_cycles; /* shader cycles spent inside cast() */
     }
 #endif
     if (ray_count != nullptr && MODE != MODE_COST) {

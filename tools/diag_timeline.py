@@ -31,7 +31,8 @@ for _ in range(3):
     assert lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), None, None) == 0
 torch.cuda.synchronize()
 t = tl.cpu().numpy()
-t0, t1, it, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+t0, t1, it, cast_cyc = t[:, 0], t[:, 1], t[:, 2] & 0xFFFF, t[:, 3]
+wave_cyc = t[:, 2] >> 16
 base = t0.min()
 s = (t0 - base) / 100.0  # us
 e = (t1 - base) / 100.0
@@ -47,6 +48,5 @@ for k in (1, 2, 3, 4, 5, 8, 12, 20, 30, 40, 50):
     m = it == k
     if m.any():
         print(f"  iterations={k:3d}: waves={m.sum():6d} mean dur {dur[m].mean():8.1f} us  ({dur[m].mean() / k:6.1f} us/iter)")
-cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
-print("  distinct (se,sh,cu):", len(set(zip(se.tolist(), sh.tolist(), cu.tolist()))))
+print(f"  share of wave cycles inside cast(): {cast_cyc.sum() / wave_cyc.sum():.3f}  (mean cast {cast_cyc.sum() / it.sum():.0f} cycles/iteration, wave {wave_cyc.sum() / it.sum():.0f} cycles/iteration)")
 np.save("gpurun_out/timeline.npy", t)

@@ -27,6 +27,11 @@ TEMPS = {f"r{k}": 2 + k for k in range(13)}
 IN = {"ox": 15, "oy": 16, "oz": 17, "dx": 18, "dy": 19, "dz": 20, "exid": 21, "keep_back": 22, "keep_front": 23,
       "ex_if_back": 24, "ex_if_front": 25, "ptr": 26, "n": 27}
 
+import sys
+EARLY_AREA_EXITS = "--no-early-area-exits" not in sys.argv
+OUT_OF_LINE_EXCLUSION = "--inline-exclusion" not in sys.argv
+SLOW = {}
+
 # fixed scalar registers (all in the clobber list)
 # (s32/s33 are the ABI stack/frame pointers and s100/s101 are reserved by the compiler: stay inside s34..s99)
 S_PTR = "s[34:35]"
@@ -104,10 +109,16 @@ def test(buf, label_next):
     # alive = bf ? keep_back : keep_front          (culling, main.rs:185-188)
     L += [f"s_and_b64 {S_ALIVE}, vcc, {op('keep_back')}", f"s_andn2_b64 {S_T1}, {op('keep_front')}, vcc", f"s_or_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}"]
     # exclusion: same primitive and (bf ? ex_if_back : ex_if_front)   (main.rs:190-200)
-    L += [f"v_cmp_eq_u32_e64 {S_T2}, {S_I}, {op('exid')}",
-          f"s_and_b64 {S_T1}, vcc, {op('ex_if_back')}", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
-          f"s_andn2_b64 {S_T1}, {op('ex_if_front')}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
-          f"s_and_b64 {S_ALIVE}, {S_ALIVE}, exec", f"s_cbranch_scc0 {label_next}"]
+    # Almost every triangle is excluded by no lane at all: test that first and keep the mask algebra out of line.
+    excl = [f"s_and_b64 {S_T1}, vcc, {op('ex_if_back')}", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
+            f"s_andn2_b64 {S_T1}, {op('ex_if_front')}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}"]
+    L += [f"v_cmp_eq_u32_e64 {S_T2}, {S_I}, {op('exid')}"]
+    if OUT_OF_LINE_EXCLUSION:
+        L += [f"s_cmp_lg_u64 {S_T2}, 0", f"s_cbranch_scc1 .Lcast_excl{buf}_%=", f".Lcast_excl{buf}_back_%=:"]
+        SLOW[buf] = [f".Lcast_excl{buf}_%=:"] + excl + [f"s_branch .Lcast_excl{buf}_back_%="]
+    else:
+        L += excl
+    L += [f"s_and_b64 {S_ALIVE}, {S_ALIVE}, exec", f"s_cbranch_scc0 {label_next}"]
     # num = d - n . o                              (main.rs:203-204)
     L += dot_sv(r[9], r[10], n, o)
     L += [f"v_sub_f32 {num}, {T['d']}, {r[9]}"]
@@ -134,12 +145,22 @@ def test(buf, label_next):
     w = (r[3], r[4], r[5])
     e0 = (T["e0x"], T["e0y"], T["e0z"]); e1 = (T["e1x"], T["e1y"], T["e1z"]); e2 = (T["e2x"], T["e2y"], T["e2z"])
     v0 = (T["v0x"], T["v0y"], T["v0z"]); v1 = (T["v1x"], T["v1y"], T["v1z"]); v2 = (T["v2x"], T["v2y"], T["v2z"])
+    # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
+    # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
+    early = EARLY_AREA_EXITS
     L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
+    if early:
+        L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
+    if early:
+        L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
-    # inside: none of the areas < 0 (NaN passes, main.rs:224) ; nearest: !(best_t < t), best_t = NaN while None
-    L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc",
-          f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    if early:
+        L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
+    else:
+        L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
+    # nearest: !(best_t < t), best_t = NaN while None (main.rs:229-233)
+    L += [f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # accept for the lanes in alive
     L += [f"s_mov_b64 {S_EXSAVE}, exec", f"s_mov_b64 exec, {S_ALIVE}",
           f"v_mov_b32 {op('best_t')}, {t}", f"v_mov_b32 {op('best_prim')}, {S_I}",
@@ -160,7 +181,10 @@ def main():
     L += loads("A", 0)
     L += test("B", ".Lcast_nextB_%=")
     L += [".Lcast_nextB_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_lt_u32 {S_I}, {S_N}", "s_cbranch_scc1 .Lcast_loop_%=",
-          ".Lcast_done_%=:", "s_waitcnt lgkmcnt(0)"]
+          "s_branch .Lcast_done_%="]
+    for b in ("A", "B"):
+        L += SLOW.get(b, [])
+    L += [".Lcast_done_%=:", "s_waitcnt lgkmcnt(0)"]
 
     clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"]
     print("/* GENERATED by tools/gen_cast_asm.py — do not edit; edit the generator. */")
