@@ -14,6 +14,7 @@ with --gpus N > 1 it starts that launcher itself as a child process.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -157,6 +158,7 @@ def main() -> int:
         dist.barrier()
     torch.cuda.synchronize()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    _capi.check(_capi.amd_lib().rt_profile_enable(1))  # HIP events around the render kernel alone, on its launch stream
     t0 = time.perf_counter()
     for e0, e1 in events:
         full = step(e0, e1)
@@ -166,7 +168,11 @@ def main() -> int:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, args.steps)
+    call_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, args.steps)  # whole call: probe + render kernels
+    ksum, kn = C.c_double(0.0), C.c_uint(0)
+    _capi.check(_capi.amd_lib().rt_profile_read(C.byref(ksum), C.byref(kn)))
+    _capi.check(_capi.amd_lib().rt_profile_enable(0))
+    kernel_ms = ksum.value / max(1, kn.value)  # rt::whitted_kernel (render) alone
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     total_casts = count.clone()
     if distributed:
@@ -223,8 +229,9 @@ def main() -> int:
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 5),
                 "traffic": traffic,
-                "kernel": "rt::whitted_kernel",
+                "kernel": "rt::whitted_kernel<8, false, 0> (the render launch; the probe launch of the same call is in call_ms_avg)",
                 "kernel_ms_avg": round(kernel_ms_max, 4),
+                "call_ms_avg": round(call_ms, 4),
                 "flop_per_cast": flop_per_cast,
                 "casts_per_launch": casts_this_rank,
                 "note": "no MFMA and not HBM-bound: the scene is 6.75 KB, the binding roof is FP32 vector issue "

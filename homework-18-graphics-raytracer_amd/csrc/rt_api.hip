@@ -35,7 +35,7 @@ struct Workspace {
     uint32_t *d_counters = nullptr; /* [0] chunk counter, [1] continuation count */
     uint32_t *d_cont = nullptr;
     size_t cont_bytes = 0;
-    uint32_t *d_tiles = nullptr; /* tile_cost[n] then tile_order[n] */
+    uint32_t *d_tiles = nullptr; /* RT_PROBE_CLASSES lists of tiles_n chunk ids */
     size_t tiles_n = 0;
 };
 
@@ -76,8 +76,8 @@ static int fail_hip(const char *what, hipError_t e) {
 static int current_variant() {
     if (g_variant < 0) {
         const char *v = getenv("RT_AMD_VARIANT");
-        g_variant = (v && *v) ? atoi(v) : RT_VARIANT_SGPR;
-        if (g_variant < 0 || g_variant > RT_VARIANT_MAX) g_variant = RT_VARIANT_SGPR;
+        g_variant = (v && *v) ? atoi(v) : RT_VARIANT_DEFAULT;
+        if (g_variant < 0 || g_variant > RT_VARIANT_MAX) g_variant = RT_VARIANT_DEFAULT;
     }
     return g_variant;
 }
@@ -111,6 +111,36 @@ int rt_set_variant(int variant) {
     return RT_OK;
 }
 int rt_get_variant(void) { return current_variant(); }
+
+/* ---- profiling of the dominant kernel ----
+ * bench.py's roofline needs the duration of the render kernel alone (a call may also launch the small probe
+ * kernel).  When enabled, every rt_render_whitted call records a HIP event pair on the launch stream right
+ * around that kernel; rt_profile_read() synchronises and sums the elapsed times. */
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+int rt_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    if (!g_prof_on) rt::set_main_kernel_events(nullptr, nullptr);
+    return RT_OK;
+}
+
+int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches) {
+    if (!kernel_ms_sum || !n_launches) return fail(RT_ERR_INVALID_ARGUMENT, "rt_profile_read: null argument");
+    RT_HIP(hipDeviceSynchronize());
+    double sum = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+        sum += ms;
+    }
+    *kernel_ms_sum = sum;
+    *n_launches = (unsigned)g_prof_used;
+    g_prof_used = 0;
+    return RT_OK;
+}
 
 int rt_set_eviction(int threshold, int min_iterations) {
     if (threshold < 0 || threshold > 63 || min_iterations < 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_eviction: threshold 0..63, min_iterations >= 0");
@@ -330,24 +360,33 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         }
         if ((variant & RT_VARIANT_SCHEME_MASK) == RT_VARIANT_SORTED) {
             const size_t chunks = (size_t)(((uint64_t)kf.cols * kf.rows + 63u) / 64u);
-            const size_t padded = (chunks + 63u) & ~(size_t)63u; /* the probe writes one cost per lane */
-            if (padded > ws.tiles_n) {
+            if (chunks > ws.tiles_n) {
                 if (ws.d_tiles) (void)hipFree(ws.d_tiles);
                 ws.d_tiles = nullptr;
                 ws.tiles_n = 0;
-                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_tiles), 2 * padded * sizeof(uint32_t)));
-                ws.tiles_n = padded;
+                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_tiles), (size_t)RT_PROBE_CLASSES * chunks * sizeof(uint32_t)));
+                ws.tiles_n = chunks;
             }
-            qs.tile_cost = ws.d_tiles;
-            qs.tile_order = ws.d_tiles + ws.tiles_n;
+            qs.tile_order = ws.d_tiles;
         }
         qs.work_queue = ws.d_counters;
         qs.cont_count = ws.d_counters + 1;
+        qs.class_count = ws.d_counters + 2;
 #ifdef RT_DIAG_TIMELINE
         qs.timeline = g_diag_timeline;
 #endif
     }
-    hipError_t e = hipMemsetAsync(qs.work_queue, 0, 2 * sizeof(uint32_t), stream);
+    if (g_prof_on) {
+        if (g_prof_used == g_prof_events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            RT_HIP(hipEventCreate(&a));
+            RT_HIP(hipEventCreate(&b));
+            g_prof_events.emplace_back(a, b);
+        }
+        rt::set_main_kernel_events(g_prof_events[g_prof_used].first, g_prof_events[g_prof_used].second);
+        g_prof_used += 1;
+    }
+    hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
     if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
     return RT_OK;

@@ -15,7 +15,7 @@
 #define RT_BLOCK_THREADS 64 /* one wave per workgroup: a finished wave frees its slot at once (256-thread groups idled 40 % of the slots) */
 #endif
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4 /* <= 128 VGPRs; measured best among 2..8 (profiles/README.md) */
+#define RT_MIN_WAVES 3 /* <= 168 VGPRs: as fast as 4 waves/SIMD (<= 128) and spills 2 registers instead of 53 (profiles/README.md) */
 #endif
 #ifdef RT_MIN_WAVES
 #define RT_LAUNCH_BOUNDS __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) /* 2nd arg: waves per SIMD */
@@ -28,11 +28,13 @@
 #define RT_VARIANT_SGPR 0 /* triangle records fetched with wave-uniform scalar loads */
 #define RT_VARIANT_LDS 1          /* bit 0: triangle records staged in LDS once per workgroup */
 #define RT_VARIANT_SCHEME_MASK 6  /* bits 1-2: how pixels reach lanes */
-#define RT_VARIANT_SORTED 0       /*   one 8x8 tile per wave, tiles dispatched most-expensive-first (cost probe + sort; default) */
-#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (the round-1 v1 scheme) */
+#define RT_VARIANT_SORTED 0       /*   one 8x8 tile per wave, tiles dispatched most-expensive-first (cost probe + class lists) */
+#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (default: as fast as SORTED once the probe is paid for) */
 #define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
 #define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
 #define RT_VARIANT_MAX 7
+#define RT_VARIANT_DEFAULT (RT_VARIANT_SGPR | RT_VARIANT_STATIC)
+#define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 
 namespace rt {
 
@@ -72,12 +74,13 @@ struct KernelQueues {
     uint32_t cont_capacity;
     uint32_t evict_threshold;      /* phase 1 leaves when at most this many lanes are still active ... */
     uint32_t evict_min_iterations; /* ... and it has done at least this many casts */
-    uint32_t *tile_cost;           /* n_chunks probe costs (RT_VARIANT_SORTED) */
-    uint32_t *tile_order;          /* n_chunks chunk ids, most expensive first */
+    uint32_t *class_count;         /* RT_PROBE_CLASSES counters (zeroed per launch): chunks filed under each cost class */
+    uint32_t *tile_order;          /* RT_PROBE_CLASSES lists of n_chunks chunk ids (RT_VARIANT_SORTED) */
     unsigned long long *timeline;  /* diagnostic builds (RT_DIAG_TIMELINE): 4 u64 per wave, else unused */
 };
 
 uint32_t cont_record_dwords(int32_t max_depth);
+void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hook, see rt_profile_* */
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                           const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);

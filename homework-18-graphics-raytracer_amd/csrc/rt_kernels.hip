@@ -361,6 +361,10 @@ struct Frame {
         }                                                                                                   \
     } while (0)
 
+#ifndef RT_PROBE_ITERS
+#define RT_PROBE_ITERS 6u /* casts the cost probe follows a pixel for (profiles/README.md) */
+#endif
+
 #ifndef RT_PRIO_STEP1
 #define RT_PRIO_STEP1 9u
 #define RT_PRIO_STEP2 14u
@@ -373,7 +377,7 @@ enum : int {
     MODE_PERSISTENT = 1, /* lanes refill pixel by pixel from a global chunk counter                          */
     MODE_PHASE1 = 2,     /* one chunk per wave; when few lanes are left their state is evicted to a queue     */
     MODE_PHASE2 = 3,     /* lanes load evicted states (continuations) from that queue, refilling as they end  */
-    MODE_COST = 4        /* probe: lane k casts the primary ray of the middle pixel of chunk k and grades what it hit */
+    MODE_COST = 4        /* probe: lane k traces the middle pixel of chunk k for a few casts and records how far it got */
 };
 
 /* A continuation = everything a lane carries between two casts: CONT_FIXED dwords + its frame stack. */
@@ -418,7 +422,16 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         /* which chunk this wave renders: dispatch position `wave`, or — when a cost-sorted order exists —
          * the wave-th most expensive chunk, so that the long tiles start first and the cheap ones fill the end */
         uint32_t chunk = wave;
-        if (MODE == MODE_STATIC && qs.tile_order != nullptr && wave < fr.n_chunks) chunk = qs.tile_order[wave];
+        if (MODE == MODE_STATIC && qs.tile_order != nullptr && wave < fr.n_chunks) {
+            /* the probe left one list of chunk ids per cost class; dispatch position `wave` walks them from the
+             * most expensive class down (a sort without a sort kernel) */
+            uint32_t pos = wave;
+            for (int32_t cls = (int32_t)RT_PROBE_ITERS + 1; cls >= 0; --cls) {
+                const uint32_t n_cls = qs.class_count[cls];
+                if (pos < n_cls) { chunk = qs.tile_order[(uint32_t)cls * fr.n_chunks + pos]; break; }
+                pos -= n_cls;
+            }
+        }
         q_next = chunk * 64u < total_slots ? chunk * 64u : total_slots;
         q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
         exhausted = true;
@@ -534,6 +547,15 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
         }
         const unsigned long long active = __builtin_amdgcn_ballot_w64(phase != PH_DONE);
         if (active == 0ull) break;
+        if (MODE == MODE_COST && iteration >= RT_PROBE_ITERS) {
+            /* the probe only has to tell long tiles from short ones: pixels still going after RT_PROBE_ITERS casts
+             * are graded "long" and the probe stops (its own latency is on the frame's critical path) */
+            if (phase != PH_DONE) {
+                const uint32_t cls = RT_PROBE_ITERS + 1u;
+                qs.tile_order[cls * fr.n_chunks + atomicAdd(&qs.class_count[cls], 1u)] = wave * 64u + lane;
+            }
+            break;
+        }
         if (MODE == MODE_PHASE1 && iteration >= qs.evict_min_iterations &&
             (uint32_t)__builtin_popcountll(active) <= qs.evict_threshold) {
             /* Few lanes left: a wave that keeps going runs the full intersection loop for a handful of
@@ -607,22 +629,7 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             V3 i_in_dir = req.d;
             uint32_t i_in_mode = req.mode;
 
-            if (MODE == MODE_COST) {
-                /* The probe stops after its primary cast and grades the tile by what it hit: transparent
-                 * surfaces spawn both children at every level (dozens of casts), mirrors one child, diffuse
-                 * surfaces only their shadow rays.  A coarse class is enough to start the long tiles first. */
-                uint32_t cls = 0u;
-                if (cr.prim >= 0) {
-                    const uint32_t obj = (uint32_t)cr.prim < sc.n_triangles ? sc.tris[cr.prim].obj : sc.spheres[(uint32_t)cr.prim - sc.n_triangles].obj;
-                    const rt_material &rm = sc.materials[obj];
-                    const float rc = rm.shiness * (1.0f - rm.transparency);
-                    cls = 1u;
-                    if (fr.max_depth > 0 && rc >= THRESHOLD) cls = 2u;
-                    if (fr.max_depth > 0 && rm.transparency > THRESHOLD) cls = rc >= THRESHOLD ? 4u : 3u;
-                }
-                qs.tile_cost[wave * 64u + lane] = cls;
-                phase = PH_DONE;
-            } else if (phase == PH_NODE) {
+            if (phase == PH_NODE) {
                 if (cr.prim < 0) {
                     value = v3(0.0f, 0.0f, 0.0f); /* main.rs:475 */
                     go = GO_RETURN;
@@ -689,7 +696,7 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             }
 
             /* small per-lane control loop; every path ends in a new cast request or PH_DONE */
-            for (; MODE != MODE_COST;) {
+            for (;;) {
                 if (go == GO_NEXT_LIGHT) {
                     /* the `for light in &self.lights` loop of get_shade up to the shadow cast (main.rs:413-433) */
                     bool issued = false;
@@ -774,14 +781,18 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
                         go = GO_RETURN;
                         continue;
                     }
-                    Frame f;
+                    /* write only what this activation will read back: the escape ray (9 of the 15 dwords) exists
+                     * only when the refraction child does — most frames are reflection-only */
+                    Frame &f = stack[sp];
                     f.rc = rc;
                     f.fc = fc;
-                    f.decay = decay;
-                    f.child_contribution = contribution * fc;
-                    f.esc_o = esc_o;
-                    f.esc_d = esc_d;
-                    f.esc_excl = esc_excl;
+                    if (has_escape) {
+                        f.decay = decay;
+                        f.child_contribution = contribution * fc;
+                        f.esc_o = esc_o;
+                        f.esc_d = esc_d;
+                        f.esc_excl = esc_excl;
+                    }
                     if (want_refl) {
                         f.acc = node_acc;
                         f.flags = 1u | (has_escape ? 2u : 0u);
@@ -798,19 +809,24 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
                         req.d = esc_d;
                         req.mode = FACE_FRONT;
                         req.excl = esc_excl;
-                        contribution = f.child_contribution;
+                        contribution = contribution * fc;
                     }
-                    stack[sp] = f;
                     sp += 1;
                     phase = PH_NODE;
                     break;
                 } else { /* GO_RETURN: unwind finished activations */
                     if (sp == 0) {
-                        /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
-                        float *px = out + (size_t)out_index * 3u;
-                        px[0] = 0.0f + value.x;
-                        px[1] = 0.0f + value.y;
-                        px[2] = 0.0f + value.z;
+                        if (MODE == MODE_COST) {
+                            /* probe finished early: its class is its exact cast count; the radiance is discarded */
+                            const uint32_t cls = casts < RT_PROBE_ITERS ? casts : RT_PROBE_ITERS;
+                            qs.tile_order[cls * fr.n_chunks + atomicAdd(&qs.class_count[cls], 1u)] = wave * 64u + lane;
+                        } else {
+                            /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
+                            float *px = out + (size_t)out_index * 3u;
+                            px[0] = 0.0f + value.x;
+                            px[1] = 0.0f + value.y;
+                            px[2] = 0.0f + value.z;
+                        }
                         phase = PH_DONE;
                         break;
                     }
@@ -863,26 +879,6 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
 
 namespace rt {
 
-/* Order the chunks by probe cost, most expensive first (counting sort on min(cost, 255); one workgroup).
- * Scheduling only: any permutation gives the same image. */
-__global__ __launch_bounds__(1024) void order_chunks_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t base[256];
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[cost[i] < 255u ? cost[i] : 255u], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0u;
-        for (int k = 255; k >= 0; --k) { base[k] = acc; acc += hist[k]; }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t k = cost[i] < 255u ? cost[i] : 255u;
-        order[atomicAdd(&base[k], 1u)] = i;
-    }
-}
-
 template <int MAXD, int MODE>
 static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                               const KernelQueues &qs, uint32_t waves, hipStream_t stream, bool use_lds) {
@@ -898,6 +894,19 @@ static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, floa
     return hipGetLastError();
 }
 
+/* optional HIP events recorded on the launch stream right around the dominant (render) kernel of a call */
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_main_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
+template <int MAXD, int MODE>
+static hipError_t launch_main(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
+                              const KernelQueues &qs, uint32_t waves, hipStream_t stream, bool use_lds) {
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, stream);
+    const hipError_t e = launch_mode<MAXD, MODE>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, stream);
+    return e;
+}
+
 template <int MAXD>
 static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const KernelQueues &qs,
                               uint32_t resident_waves, hipStream_t stream, int variant) {
@@ -908,25 +917,23 @@ static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out,
     if (scheme == RT_VARIANT_STATIC) {
         KernelQueues q2 = qs;
         q2.tile_order = nullptr;
-        return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
+        return launch_main<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
     }
     if (scheme == RT_VARIANT_SORTED) {
-        /* 1. probe one pixel per chunk, 2. order chunks by probe cost, 3. render, most expensive chunks first */
+        /* 1. probe: follow the middle pixel of every chunk for a few casts and file the chunk under its cost class,
+         * 2. render, walking the class lists from the most expensive class down */
         if (fr.n_chunks <= resident_waves || qs.tile_order == nullptr) { /* everything is resident at once: order is moot */
             KernelQueues q2 = qs;
             q2.tile_order = nullptr;
-            return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
+            return launch_main<MAXD, MODE_STATIC>(sc, fr, out, ray_count, q2, fr.n_chunks, stream, use_lds);
         }
         hipError_t e = launch_mode<MAXD, MODE_COST>(sc, fr, out, ray_count, qs, (fr.n_chunks + 63u) / 64u, stream, use_lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(1024), 0, stream, qs.tile_cost, qs.tile_order, fr.n_chunks);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        return launch_mode<MAXD, MODE_STATIC>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
+        return launch_main<MAXD, MODE_STATIC>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
     }
     if (scheme == RT_VARIANT_PERSISTENT) {
         const uint32_t waves = fr.n_chunks < resident_waves ? fr.n_chunks : resident_waves;
-        return launch_mode<MAXD, MODE_PERSISTENT>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
+        return launch_main<MAXD, MODE_PERSISTENT>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
     }
     /* two-phase (default): coherent tiles that evict their stragglers, then the stragglers packed 64 per wave */
     hipError_t e = launch_mode<MAXD, MODE_PHASE1>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);

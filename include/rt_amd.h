@@ -222,12 +222,12 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
 /* Kernel variant used by the render entry points of this process (bit field):
  *   bit 0     0: triangle records fetched with wave-uniform scalar loads (SGPR broadcast)
  *             1: triangle records staged in LDS once per workgroup (LDS broadcast)
- *   bits 1-2  0: one 8x8 tile per wave, tiles dispatched most-expensive-first: a probe traces one pixel
- *                per tile, a counting sort orders the tiles by the probe's cast count (default)
- *             2: one 8x8 tile per wave, dispatched in image order
+ *   bits 1-2  0: one 8x8 tile per wave, tiles dispatched most-expensive-first: a probe follows one pixel
+ *                per tile for a few casts and files the tile under a cost class
+ *             2: one 8x8 tile per wave, dispatched in image order (default)
  *             4: persistent waves, lanes refill pixel by pixel from a work queue
  *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
- * Default 0, or the value of the RT_AMD_VARIANT environment variable at load. */
+ * Default 2, or the value of the RT_AMD_VARIANT environment variable at load. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);
 
@@ -235,6 +235,13 @@ int rt_get_variant(void);
  * and it has done at least `min_iterations` casts.  Defaults 16 / 4 (RT_AMD_EVICT_THRESHOLD,
  * RT_AMD_EVICT_MIN_ITER).  Changes scheduling only, never results. */
 int rt_set_eviction(int threshold, int min_iterations);
+
+/* Timing of the dominant (render) kernel alone: while enabled, each rt_render_whitted call records a HIP
+ * event pair on its stream right around that kernel (a call may also launch a small probe kernel);
+ * rt_profile_read synchronises the device, returns the summed elapsed milliseconds and the number of
+ * launches since the last read, and resets. */
+int rt_profile_enable(int on);
+int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches);
 
 /* The deterministic f32 math the path computes with (csrc/rt_detmath.h),
  * evaluated element-wise on the host or on the device, so tests can prove the

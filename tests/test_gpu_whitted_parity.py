@@ -30,7 +30,7 @@ def _compare(world, camera, scene, frame, variant=0):
     try:
         got, casts = rt.render_whitted_numpy(scene, camera, frame)
     finally:
-        _capi.check(_capi.amd_lib().rt_set_variant(0))
+        _capi.check(_capi.amd_lib().rt_set_variant(2))
     want, want_casts = _oracle.render_whitted(world.desc(), camera, frame)
     diff = got.view(np.uint32) != want.view(np.uint32)
     if diff.any():

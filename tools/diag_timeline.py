@@ -28,7 +28,7 @@ out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
 lib.rt_set_variant(variant)
 lib.rt_diag_set_timeline(C.c_void_p(tl.data_ptr()))
 for _ in range(3):
-    assert lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), None, None) == 0
+    assert lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), None, None) == 0, lib.rt_last_error()
 torch.cuda.synchronize()
 t = tl.cpu().numpy()
 t0, t1, it, cast_cyc = t[:, 0], t[:, 1], t[:, 2] & 0xFFFF, t[:, 3]
