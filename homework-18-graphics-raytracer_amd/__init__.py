@@ -25,7 +25,7 @@ from ._capi import Camera, Frame, Light, Material, RtError, SceneDesc, Sphere, T
 
 __all__ = [
     "World", "ObjectProxy", "Scene", "Camera", "Frame", "Material", "Light", "RtError", "reference_world",
-    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "post_process", "encode_srgb8", "write_to_file",
+    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "post_process_device", "encode_srgb8_device", "post_process", "encode_srgb8", "write_to_file",
     "DEFAULT_OBJ",
 ]
 
@@ -230,6 +230,29 @@ def render_distributed(scene: Scene, camera: Camera, frame: Frame, rng: Rng, n_e
                                               int(n_epochs), ptr(accum), ptr(samples), ptr(valid), ptr(ray_count), C.c_void_p(s.cuda_stream))
     )
     return accum if accum is not None else samples
+
+
+def post_process_device(img, divisor=None, stream=None):
+    """In-place p99-luma normalisation of a (rows, cols, 3) f32 CUDA tensor (src/main.rs:748-762), on the device."""
+    import torch
+
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and img.shape[-1] == 3
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _capi.check(_capi.amd_lib().rt_post_process_device(C.c_void_p(img.data_ptr()), img.numel() // 3,
+                                                      None if divisor is None else C.c_void_p(divisor.data_ptr()), C.c_void_p(s.cuda_stream)))
+    return img
+
+
+def encode_srgb8_device(img, out=None, stream=None):
+    """Linear f32 -> sRGB u8 on the device (src/image.rs:55-66)."""
+    import torch
+
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+    if out is None:
+        out = torch.empty(img.shape, dtype=torch.uint8, device=img.device)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _capi.check(_capi.amd_lib().rt_encode_srgb8_device(C.c_void_p(img.data_ptr()), img.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
+    return out
 
 
 def post_process(img: np.ndarray) -> float:

@@ -124,7 +124,7 @@ AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
     "rt_get_variant", "rt_set_eviction", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
-    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed",
+    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_post_process_device", "rt_encode_srgb8_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
@@ -198,6 +198,8 @@ def amd_lib() -> C.CDLL:
         lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_render_whitted_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_ulonglong)]
         lib.rt_set_variant.argtypes = [C.c_int]
+        lib.rt_post_process_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.rt_encode_srgb8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_rng_create.argtypes = [C.POINTER(Frame), C.POINTER(C.c_void_p)]
         lib.rt_rng_destroy.argtypes = [C.c_void_p]
         lib.rt_rng_download.argtypes = [C.c_void_p, C.c_void_p]

@@ -23,6 +23,7 @@
 #include "rt_device_scene.h"
 #include "rt_kernels.h"
 #include "rt_vec.h"
+#include "rt_luma.h"
 
 namespace rt {
 void math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
@@ -497,6 +498,49 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.ray_count = d_ray_count;
     hipError_t e = rt::launch_distributed(scene->ks, kf, dp, static_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
+    return RT_OK;
+}
+
+/* ---- post_process / encode on the device ----------------------------------------- */
+
+struct PostWs {
+    uint32_t *d_keys = nullptr;
+    size_t n = 0;
+    uint32_t *d_state = nullptr;
+};
+static std::mutex g_post_mutex;
+static std::map<hipStream_t, PostWs> g_post_ws;
+
+int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void *hip_stream) {
+    if (!d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_process_device: null argument");
+    if (n_pixels == 0) return RT_OK;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    uint32_t *keys = nullptr, *state = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_post_mutex);
+        PostWs &ws = g_post_ws[stream];
+        if (!ws.d_state) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_state), 260 * sizeof(uint32_t)));
+        if (n_pixels > ws.n) {
+            if (ws.d_keys) (void)hipFree(ws.d_keys);
+            ws.d_keys = nullptr;
+            ws.n = 0;
+            RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_keys), n_pixels * sizeof(uint32_t)));
+            ws.n = n_pixels;
+        }
+        keys = ws.d_keys;
+        state = ws.d_state;
+    }
+    float row[3];
+    rt::luma_row(row);
+    hipError_t e = rt::launch_post_process(d_rgb, n_pixels, row, keys, state, d_divisor, stream);
+    if (e != hipSuccess) return fail_hip("rt_post_process_device: launch", e);
+    return RT_OK;
+}
+
+int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream) {
+    if (!d_rgb || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_encode_srgb8_device: null argument");
+    hipError_t e = rt::launch_encode_srgb8(d_rgb, n_values, d_out, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_encode_srgb8_device: launch", e);
     return RT_OK;
 }
 

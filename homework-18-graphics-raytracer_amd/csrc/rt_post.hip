@@ -1,0 +1,145 @@
+/*
+ * rt_post.hip — the step right after the render path, on the device:
+ *   post_process   src/main.rs:748-762   divide the image by the 99th-percentile luma of its normal lumas
+ *   convert_from   src/image.rs:55-66    linear -> sRGB transfer, f32 -> u8
+ *
+ * The reference sorts all lumas to index one element; selecting the k-th smallest is order independent, so an
+ * exact radix select gives the same value: 4 passes over order-preserving 32-bit keys, 8 bits per pass, each pass
+ * a histogram of the keys that still match the chosen prefix.  HBM-bound byte work: one coalesced read of the
+ * key array per pass (8 MB at 1080p), no sort.  The arithmetic (luma row, divide, transfer function, truncating
+ * u8 cast) is the host's (rt_host.cpp) operation for operation, so results are bit-identical to it and to the oracle.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_detmath.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+#define KEY_INVALID 0xffffffffu
+
+/* monotone map f32 -> u32 (negative floats reversed below the positives) */
+__device__ __forceinline__ uint32_t order_key(float x) {
+    const uint32_t b = rtdm::f32_bits(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return rtdm::f32_from_bits(b);
+}
+
+/* state[0] = number of normal lumas, state[1] = k (0-based rank wanted), state[2] = chosen key prefix,
+ * state[3] = result key, state[4..259] = histogram */
+__global__ void post_keys_kernel(const float *__restrict__ rgb, uint32_t *__restrict__ keys, size_t n, float r0, float r1, float r2,
+                                 uint32_t *__restrict__ state) {
+    uint32_t local = 0u;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        /* into_luma: the Y row of palette's rgb->xyz matrix, (c3*r + c4*g) + c5*b */
+        const float l = (r0 * rgb[3 * i] + r1 * rgb[3 * i + 1]) + r2 * rgb[3 * i + 2];
+        const bool ok = rtdm::is_normal(l); /* main.rs:751 */
+        keys[i] = ok ? order_key(l) : KEY_INVALID;
+        local += ok ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63u) == 0u && local != 0u) atomicAdd(&state[0], local);
+}
+
+__global__ void post_rank_kernel(uint32_t *state) {
+    /* (luma_cumulative.len() as f32 * 0.99) as usize, main.rs:754 */
+    const uint32_t len = state[0];
+    uint32_t k = (uint32_t)((float)len * 0.99f);
+    if (len != 0u && k >= len) k = len - 1u;
+    state[1] = k;
+    state[2] = 0u;
+    state[3] = KEY_INVALID;
+}
+
+__global__ void post_hist_kernel(const uint32_t *__restrict__ keys, size_t n, int pass, uint32_t *__restrict__ state) {
+    __shared__ uint32_t hist[256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    const uint32_t prefix = state[2];
+    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = keys[i];
+        if (k != KEY_INVALID && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x)
+        if (hist[i] != 0u) atomicAdd(&state[4 + i], hist[i]);
+}
+
+__global__ void post_pick_kernel(int pass, uint32_t *state) {
+    if (threadIdx.x != 0) return;
+    if (state[0] == 0u) return;
+    const int shift = 24 - 8 * pass;
+    uint32_t k = state[1];
+    uint32_t digit = 255u;
+    for (uint32_t d = 0; d < 256u; ++d) {
+        const uint32_t c = state[4 + d];
+        if (k < c) { digit = d; break; }
+        k -= c;
+    }
+    state[1] = k;
+    state[2] |= digit << shift;
+    for (uint32_t d = 0; d < 256u; ++d) state[4 + d] = 0u;
+    if (pass == 3) state[3] = state[2];
+}
+
+__global__ void post_scale_kernel(float *__restrict__ rgb, size_t n_values, const uint32_t *__restrict__ state, float *__restrict__ divisor_out) {
+    const bool have = state[0] != 0u;
+    const float p98 = have ? key_value(state[3]) : 0.0f;
+    const bool apply = have && p98 > 1.1920928955078125e-7f; /* main.rs:755 */
+    if (blockIdx.x == 0 && threadIdx.x == 0 && divisor_out != nullptr) *divisor_out = apply ? p98 : 0.0f;
+    if (!apply) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) rgb[i] = rgb[i] / p98;
+}
+
+__global__ void encode_srgb8_kernel(const float *__restrict__ rgb, size_t n_values, unsigned char *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
+        const float x = rgb[i];
+        const float e = (x <= 0.0031308f) ? 12.92f * x : 1.055f * rtdm::powf(x, 1.0f / 2.4f) - 0.055f;
+        float r = e * 255.0f; /* palette 0.4 f32 -> u8: scale, clamp, truncate */
+        if (!(r > 0.0f)) r = 0.0f;
+        if (r > 255.0f) r = 255.0f;
+        out[i] = (unsigned char)r;
+    }
+}
+
+static unsigned grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048; /* grid-stride the rest (memory-bound: 256 CUs x 8 blocks) */
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+/* keys: n_pixels u32; state: 260 u32 (zeroed here) */
+hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,
+                               float *divisor_out, hipStream_t stream) {
+    if (n_pixels == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(state, 0, 260 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(post_keys_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, rgb, keys, n_pixels, luma_row[0], luma_row[1],
+                       luma_row[2], state);
+    hipLaunchKernelGGL(post_rank_kernel, dim3(1), dim3(1), 0, stream, state);
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(post_hist_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, keys, n_pixels, pass, state);
+        hipLaunchKernelGGL(post_pick_kernel, dim3(1), dim3(64), 0, stream, pass, state);
+    }
+    hipLaunchKernelGGL(post_scale_kernel, dim3(grid_for(n_pixels * 3)), dim3(256), 0, stream, rgb, n_pixels * 3, state, divisor_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_srgb8(const float *rgb, size_t n_values, unsigned char *out, hipStream_t stream) {
+    if (n_values == 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_srgb8_kernel, dim3(grid_for(n_values)), dim3(256), 0, stream, rgb, n_values, out);
+    return hipGetLastError();
+}
+
+} /* namespace rt */

@@ -68,3 +68,18 @@ def render_frame_sharded(render_band: Callable[[Frame], "object"], width: int, h
     frame = shard_frame(width, height, max_depth, rank, world)
     band = render_band(frame)
     return gather_frame(band, height, rank, world, dst=dst, group=group, staging=staging)
+
+
+def accumulate_epochs_sharded(render_epochs: Callable[[Frame], "object"], width: int, height: int, max_depth: int, rank: int,
+                              world: int, dst: int = 0, group=None, staging=None):
+    """The distributed (stochastic) pass over N ranks — BASELINE.json configs[3]/[4].
+
+    Pixels own their RNG streams (seed y*2^33 + x, src/main.rs:1119), so a rank keeps the IsaacRng states of
+    its row band for all epochs and nothing but the accumulated band ever moves: `render_epochs(frame)` runs
+    any number of epochs on this rank's band (rt.render_distributed with accum=..., RNG created for `frame`)
+    and returns the (band_rows, width, 3) sum; the bands are gathered to `dst` exactly like a Whitted frame.
+    The result equals the single-process sum bit for bit because every pixel's samples are added in the same
+    epoch order regardless of which rank owns it.
+    """
+    frame = shard_frame(width, height, max_depth, rank, world)
+    return gather_frame(render_epochs(frame), height, rank, world, dst=dst, group=group, staging=staging)

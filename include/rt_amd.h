@@ -217,6 +217,16 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                           rt_rng *rng, uint32_t n_epochs, float *d_accum, float *d_samples, unsigned char *d_valid,
                           unsigned long long *d_ray_count, void *hip_stream);
 
+/* ---- the step after the path, on the device --------------------
+
+ * post_process (src/main.rs:748-762): divide the image in place by the 99th-percentile luma of its normal
+ * lumas (exact radix select; no sort).  *d_divisor (device float, may be NULL) receives the divisor used, 0 when
+ * the image was left untouched (no normal luma, or percentile <= f32::EPSILON).  Bit-identical to
+ * rt_post_process in librt_host.so.  Stream-ordered. */
+int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void *hip_stream);
+/* Image::<Srgb<u8>>::convert_from (src/image.rs:55-66): linear f32 -> sRGB-encoded u8, n_values = 3*pixels. */
+int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 
 /* Kernel variant used by the render entry points of this process (bit field):

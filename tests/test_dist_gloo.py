@@ -65,6 +65,52 @@ def test_sharded_frame_equals_single_process(tmp_path, world, w, h):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def _dist_worker(rank, world, port, w, h, depth, epochs, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+    import _oracle
+
+    wd = rt.reference_world()
+    cam = rt.reference_camera()
+
+    def render_epochs(frame):
+        st = _oracle.rng_init(frame)  # this rank's pixels only; seeds come from IMAGE coordinates
+        s, v, _ = _oracle.render_distributed(wd.desc(), cam, frame, st, epochs, threads=2)
+        acc = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+        for e in range(epochs):
+            acc = np.where(v[e][..., None] != 0, acc + s[e], acc)
+        return torch.from_numpy(acc)
+
+    full = rtdist.accumulate_epochs_sharded(render_epochs, w, h, depth, rank, world, dst=0)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_distributed_pass_equals_single_process(tmp_path):
+    """configs[3]: each rank keeps the RNG states of its own rows; the gathered sum equals the one-process sum."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import homework_18_graphics_raytracer_amd as rt
+    import _oracle
+
+    w, h, depth, epochs, world = 48, 36, 5, 3, 2
+    out = tmp_path / "acc.npy"
+    mp.spawn(_dist_worker, args=(world, _free_port(), w, h, depth, epochs, str(out)), nprocs=world, join=True)
+    frame = rt.Frame.full(w, h, depth)
+    st = _oracle.rng_init(frame)
+    s, v, _ = _oracle.render_distributed(rt.reference_world().desc(), rt.reference_camera(), frame, st, epochs)
+    want = np.zeros((h, w, 3), dtype=np.float32)
+    for e in range(epochs):
+        want = np.where(v[e][..., None] != 0, want + s[e], want)
+    assert np.array_equal(np.load(out).view(np.uint32), want.view(np.uint32))
+
+
 def test_shard_arithmetic():
     import homework_18_graphics_raytracer_amd as rt
     from homework_18_graphics_raytracer_amd import dist as rtdist
