@@ -15,16 +15,18 @@ from homework_18_graphics_raytracer_amd import _capi
 
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 lib = C.CDLL(str(_capi.PKG_DIR / "variants/librt_amd_diag.so"))
 lib.rt_scene_create.argtypes = [C.POINTER(_capi.SceneDesc), C.POINTER(C.c_void_p)]
 lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(_capi.Camera), C.POINTER(_capi.Frame), C.c_void_p, C.c_void_p, C.c_void_p]
 lib.rt_diag_set_timeline.argtypes = [C.c_void_p]
 world = rt.reference_world(); cam = rt.reference_camera(); desc = world.desc()
-frame = rt.Frame.full(1920, 1080, depth)
+frame = rt.Frame.full(W, H, depth)
 h = C.c_void_p(); assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0
-n_waves = (1920 * 1080 + 63) // 64
+n_waves = (W * H + 63) // 64
 tl = torch.zeros((n_waves, 4), dtype=torch.int64, device="cuda")
-out = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 lib.rt_set_variant(variant)
 lib.rt_diag_set_timeline(C.c_void_p(tl.data_ptr()))
 for _ in range(3):

@@ -30,6 +30,8 @@ IN = {"ox": 15, "oy": 16, "oz": 17, "dx": 18, "dy": 19, "dz": 20, "exid": 21, "k
 import sys
 EARLY_AREA_EXITS = "--no-early-area-exits" not in sys.argv
 OUT_OF_LINE_EXCLUSION = "--inline-exclusion" not in sys.argv
+ILP = "--ilp" in sys.argv  # interleave the three signed-area chains (and p) for a lone wave; one exit after all three
+XT = [f"v{k}" for k in range(148, 168)]  # extra temporaries of the ILP form: fixed VGPRs, named in the clobber list
 SLOW = {}
 
 # fixed scalar registers (all in the clobber list)
@@ -140,25 +142,41 @@ def test(buf, label_next):
     L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # p = o + d * t
     p = (r[0], r[1], r[2])
-    for k in range(3):
-        L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
+    if ILP:
+        L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}" for k in range(3)] + [f"v_add_f32 {p[k]}, {o[k]}, {p[k]}" for k in range(3)]
+    else:
+        for k in range(3):
+            L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
     w = (r[3], r[4], r[5])
     e0 = (T["e0x"], T["e0y"], T["e0z"]); e1 = (T["e1x"], T["e1y"], T["e1z"]); e2 = (T["e2x"], T["e2y"], T["e2z"])
     v0 = (T["v0x"], T["v0y"], T["v0z"]); v1 = (T["v1x"], T["v1y"], T["v1z"]); v2 = (T["v2x"], T["v2y"], T["v2z"])
-    # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
-    # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
-    early = EARLY_AREA_EXITS
-    L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
-    if early:
-        L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
-    L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
-    if early:
-        L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
-    L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
-    if early:
-        L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
-    else:
+    if ILP:
+        # p = o + d*t was emitted component by component above; the three areas are independent chains: give each
+        # its own temporaries and issue them round-robin so a lone wave always has an independent instruction next
+        chains = [
+            area(r[6], e0, v1, p, (XT[0], XT[1], XT[2]), (r[6], XT[3], XT[4]), XT[5], n),
+            area(r[7], e1, v2, p, (XT[6], XT[7], XT[8]), (r[7], XT[9], XT[10]), XT[11], n),
+            area(r[8], e2, v0, p, (XT[12], XT[13], XT[14]), (r[8], XT[15], XT[16]), XT[17], n),
+        ]
+        for k in range(len(chains[0])):
+            for c in chains:
+                L.append(c[k])
         L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
+    else:
+        # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
+        # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
+        early = EARLY_AREA_EXITS
+        L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
+        if early:
+            L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+        L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
+        if early:
+            L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+        L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
+        if early:
+            L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
+        else:
+            L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
     # nearest: !(best_t < t), best_t = NaN while None (main.rs:229-233)
     L += [f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # accept for the lanes in alive
@@ -186,7 +204,7 @@ def main():
         L += SLOW.get(b, [])
     L += [".Lcast_done_%=:", "s_waitcnt lgkmcnt(0)"]
 
-    clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"]
+    clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"] + (XT[:18] if ILP else [])
     print("/* GENERATED by tools/gen_cast_asm.py — do not edit; edit the generator. */")
     print("#ifndef RT_CAST_ASM_H")
     print("#define RT_CAST_ASM_H")
