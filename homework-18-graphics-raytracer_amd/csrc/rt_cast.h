@@ -120,8 +120,10 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
  * the sphere loop (main.rs:264-324) stays in C++. */
 #include "rt_cast_asm.h"
 
-__device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
-    const uint32_t nt = sc.n_triangles;
+/* The asm part over the triangle range [index_base, index_base + n): returns the range's nearest accepted hit
+ * under the reference's sequential rule, as (best_t, best_prim) with best_prim a GLOBAL triangle index or -1. */
+__device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uint32_t n, uint32_t index_base, const Ray &ray,
+                                                   float *out_t, int32_t *out_prim) {
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
     const uint32_t ex_face = (ray.excl >> 29) & 3u;
@@ -130,18 +132,32 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
     const unsigned long long keep_front = __builtin_amdgcn_ballot_w64(ray.mode != FACE_BACK);
     const unsigned long long ex_if_back = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_FRONT);  /* Back or Both */
     const unsigned long long ex_if_front = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_BACK);  /* Front or Both */
-    const uint32_t exid = (ex_some && ex_prim < nt) ? ex_prim : 0xffffffffu;
+    const uint32_t exid = (ex_some && ex_prim >= index_base && ex_prim - index_base < n) ? ex_prim - index_base : 0xffffffffu;
     float best_t = rtdm::quiet_nan();
     int32_t best_prim = -1;
     float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12;
-    const unsigned long long ptr = (unsigned long long)(uintptr_t)sc.tris;
+    /* the range is wave-uniform by construction; say so, so that it is passed in SGPRs */
+    const unsigned long long ptr_v = (unsigned long long)(uintptr_t)tris_range;
+    const unsigned long long ptr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ptr_v >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ptr_v);
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
     asm volatile(RT_CAST_ASM_TEXT
                  : "+v"(best_t), "+v"(best_prim), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6),
                    "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12)
                  : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(keep_back),
-                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(nt)
+                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(n)
                  : RT_CAST_ASM_CLOBBERS);
+    *out_t = best_t;
+    *out_prim = best_prim >= 0 ? best_prim + (int32_t)index_base : -1;
+}
 
+/* Everything of World::cast after the triangle loop: the winner's backface flag and signed areas, then the
+ * sphere loop (main.rs:264-324), starting from the triangles' nearest hit. */
+__device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim) {
+    const uint32_t nt = sc.n_triangles;
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
     CastResult best;
     best.prim = best_prim;
     best.t = best_t;
@@ -184,6 +200,13 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
         best.bf = bf ? 1u : 0u;
     }
     return best;
+}
+
+__device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
+    float best_t;
+    int32_t best_prim;
+    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, &best_t, &best_prim);
+    return cast_finish(sc, ray, best_t, best_prim);
 }
 
 /* What the state machine keeps of a Hit (main.rs:139-147). */

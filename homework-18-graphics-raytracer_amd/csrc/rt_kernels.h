@@ -32,7 +32,8 @@
 #define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (default: as fast as SORTED once the probe is paid for) */
 #define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
 #define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
-#define RT_VARIANT_MAX 7
+#define RT_VARIANT_COOP 8         /* bit 3: cooperative workgroups — four waves split every tile's triangle loop */
+#define RT_VARIANT_MAX 15
 #define RT_VARIANT_DEFAULT (RT_VARIANT_SGPR | RT_VARIANT_STATIC)
 #define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 

@@ -361,6 +361,13 @@ struct Frame {
         }                                                                                                   \
     } while (0)
 
+/* cooperative cast (MODE_COOP): LDS layout in dwords */
+#define COOP_WAVES 4u
+#define COOP_RAYS_OFFSET 0u                                  /* [tile][8][64] */
+#define COOP_RES_OFFSET (COOP_WAVES * 8u * 64u)              /* [tile][chunk][2][64] */
+#define COOP_MASK_OFFSET (COOP_RES_OFFSET + COOP_WAVES * COOP_WAVES * 2u * 64u) /* [tile][2] */
+#define COOP_LDS_BYTES ((COOP_MASK_OFFSET + COOP_WAVES * 2u) * 4u)
+
 #ifndef RT_PROBE_ITERS
 #define RT_PROBE_ITERS 6u /* casts the cost probe follows a pixel for (profiles/README.md) */
 #endif
@@ -377,6 +384,7 @@ enum : int {
     MODE_PERSISTENT = 1, /* lanes refill pixel by pixel from a global chunk counter                          */
     MODE_PHASE1 = 2,     /* one chunk per wave; when few lanes are left their state is evicted to a queue     */
     MODE_PHASE2 = 3,     /* lanes load evicted states (continuations) from that queue, refilling as they end  */
+    MODE_COOP = 5,       /* 256-thread workgroups of four tiles; the waves split every tile's triangle loop four ways (below) */
     MODE_COST = 4        /* probe: lane k traces the middle pixel of chunk k for a few casts and records how far it got */
 };
 
@@ -385,8 +393,8 @@ enum : int {
 #define FRAME_DWORDS 15u
 
 template <int MAXD, bool USE_LDS, int MODE>
-__global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr, float *__restrict__ out,
-                                                unsigned long long *__restrict__ ray_count, const KernelQueues qs) {
+__device__ __forceinline__ void whitted_body(const KernelScene &sc, const KernelFrame &fr, float *__restrict__ out,
+                                             unsigned long long *__restrict__ ray_count, const KernelQueues &qs) {
     uint32_t *__restrict__ work_queue = qs.work_queue;
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     const DevTri *lds_tris = nullptr;
@@ -418,6 +426,16 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
     const uint32_t band_slots = fr.cols << 3;
     uint32_t q_next = 0u, q_end = 0u;
     bool exhausted = false;
+    /* MODE_COOP: a workgroup of COOP_WAVES waves owns COOP_WAVES tiles taken from far-apart parts of the image
+     * (tile = group + k * n_groups), so that cheap and expensive tiles share a group; see "cooperative cast". */
+    const uint32_t wslot = (threadIdx.x >> 6);
+    uint32_t *coop_lds = reinterpret_cast<uint32_t *>(lds_raw);
+    if (MODE == MODE_COOP) {
+        const uint32_t chunk = blockIdx.x + wslot * gridDim.x;
+        q_next = chunk < fr.n_chunks ? chunk * 64u : total_slots;
+        q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
+        exhausted = true;
+    }
     if (MODE == MODE_STATIC || MODE == MODE_PHASE1) {
         /* which chunk this wave renders: dispatch position `wave`, or — when a cost-sorted order exists —
          * the wave-th most expensive chunk, so that the long tiles start first and the cheap ones fill the end */
@@ -546,7 +564,23 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
             }
         }
         const unsigned long long active = __builtin_amdgcn_ballot_w64(phase != PH_DONE);
-        if (active == 0ull) break;
+        if (MODE == MODE_COOP) {
+            /* publish this tile's 64 ray requests and its live-lane mask, then decide together whether anyone is left */
+            uint32_t *my = coop_lds + COOP_RAYS_OFFSET + (wslot * 8u) * 64u + lane;
+            my[0 * 64] = __float_as_uint(req.o.x); my[1 * 64] = __float_as_uint(req.o.y); my[2 * 64] = __float_as_uint(req.o.z);
+            my[3 * 64] = __float_as_uint(req.d.x); my[4 * 64] = __float_as_uint(req.d.y); my[5 * 64] = __float_as_uint(req.d.z);
+            my[6 * 64] = req.mode; my[7 * 64] = req.excl;
+            if (lane == 0u) {
+                coop_lds[COOP_MASK_OFFSET + wslot * 2u] = (uint32_t)active;
+                coop_lds[COOP_MASK_OFFSET + wslot * 2u + 1u] = (uint32_t)(active >> 32);
+            }
+            __syncthreads();
+            uint32_t any = 0u;
+            for (uint32_t j = 0; j < COOP_WAVES * 2u; ++j) any |= coop_lds[COOP_MASK_OFFSET + j];
+            if (__builtin_amdgcn_readfirstlane((int)any) == 0) break;
+        } else if (active == 0ull) {
+            break;
+        }
         if (MODE == MODE_COST && iteration >= RT_PROBE_ITERS) {
             /* the probe only has to tell long tiles from short ones: pixels still going after RT_PROBE_ITERS casts
              * are graded "long" and the probe stops (its own latency is on the frame's critical path) */
@@ -607,9 +641,62 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
 #elif defined(RT_CAST_COMPILER) /* the compiler-generated loop (round-1 v1..v3) */
             cr = cast<USE_LDS>(sc, lds_tris, req);
 #else
-            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_asm(sc, req);
+            if (MODE != MODE_COOP) cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_asm(sc, req);
 #endif
             casts += 1u;
+        }
+        if (MODE == MODE_COOP) {
+            /* ---- cooperative cast ----
+             * The frame's critical path is its deepest tile: ~50 dependent casts, each a 64-triangle loop that one
+             * wave cannot run faster than ~12 us.  Here the four waves of a group split EVERY tile's loop: wave w
+             * tests triangles [w*nt/4, (w+1)*nt/4) for the rays of each tile that is still alive, so a tile whose
+             * three neighbours have finished gets its casts done four times sooner, and a group with four live
+             * tiles does the same total work as before.  Rays and partial results go through LDS (16 KB).
+             * Merging the four partial (t, prim) in triangle order with the reference's own rule
+             * (`nearest_t < t -> skip`, ties to the later primitive) equals the sequential scan — except when a
+             * candidate distance is NaN (degenerate geometry), where the scan's history matters: then the owning
+             * wave simply redoes its cast sequentially. */
+            const uint32_t nt = sc.n_triangles;
+            const uint32_t per = (nt + COOP_WAVES - 1u) / COOP_WAVES;
+            const uint32_t t_base = wslot * per < nt ? wslot * per : nt;
+            const uint32_t t_cnt = t_base + per < nt ? per : nt - t_base;
+            for (uint32_t j = 0; j < COOP_WAVES; ++j) {
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)coop_lds[COOP_MASK_OFFSET + j * 2u]);
+                const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)coop_lds[COOP_MASK_OFFSET + j * 2u + 1u]);
+                const unsigned long long mj = ((unsigned long long)mhi << 32) | mlo;
+                if (mj == 0ull) continue;
+                float bt = rtdm::quiet_nan();
+                int32_t bp = -1;
+                if ((mj >> lane) & 1ull) {
+                    const uint32_t *rj = coop_lds + COOP_RAYS_OFFSET + (j * 8u) * 64u + lane;
+                    Ray r;
+                    r.o = v3(__uint_as_float(rj[0 * 64]), __uint_as_float(rj[1 * 64]), __uint_as_float(rj[2 * 64]));
+                    r.d = v3(__uint_as_float(rj[3 * 64]), __uint_as_float(rj[4 * 64]), __uint_as_float(rj[5 * 64]));
+                    r.mode = rj[6 * 64];
+                    r.excl = rj[7 * 64];
+                    cast_asm_triangles(sc.tris + t_base, t_cnt, t_base, r, &bt, &bp);
+                }
+                uint32_t *res = coop_lds + COOP_RES_OFFSET + ((j * COOP_WAVES + wslot) * 2u) * 64u + lane;
+                res[0] = __float_as_uint(bt);
+                res[64] = (uint32_t)bp;
+            }
+            __syncthreads();
+            if (phase != PH_DONE) {
+                float best_t = rtdm::quiet_nan();
+                int32_t best_prim = -1;
+                bool saw_nan = false;
+                for (uint32_t c = 0; c < COOP_WAVES; ++c) {
+                    const uint32_t *res = coop_lds + COOP_RES_OFFSET + ((wslot * COOP_WAVES + c) * 2u) * 64u + lane;
+                    const float t = __uint_as_float(res[0]);
+                    const int32_t pr = (int32_t)res[64];
+                    if (pr >= 0) {
+                        saw_nan = saw_nan || (t != t);
+                        if (!(best_prim >= 0 && best_t < t)) { best_t = t; best_prim = pr; }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(saw_nan) != 0ull) cast_asm_triangles(sc.tris, nt, 0u, req, &best_t, &best_prim);
+                cr = cast_finish(sc, req, best_t, best_prim);
+            }
         }
 #ifdef RT_DIAG_TIMELINE
         diag_cast_cycles += __builtin_amdgcn_s_memtime() - diag_ca;
@@ -873,6 +960,21 @@ __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const Kern
     }
 }
 
+template <int MAXD, bool USE_LDS, int MODE>
+__global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr, float *__restrict__ out,
+                                                unsigned long long *__restrict__ ray_count, const KernelQueues qs) {
+    whitted_body<MAXD, USE_LDS, MODE>(sc, fr, out, ray_count, qs);
+}
+
+/* the cooperative variant: 256-thread workgroups (four waves, four tiles), same body */
+template <int MAXD>
+__global__ __launch_bounds__(COOP_WAVES * 64, RT_MIN_WAVES) void whitted_coop_kernel(const KernelScene sc, const KernelFrame fr,
+                                                                                      float *__restrict__ out,
+                                                                                      unsigned long long *__restrict__ ray_count,
+                                                                                      const KernelQueues qs) {
+    whitted_body<MAXD, false, MODE_COOP>(sc, fr, out, ray_count, qs);
+}
+
 } /* namespace rt */
 
 /* ---- launchers ------------------------------------------------------------------ */
@@ -930,6 +1032,14 @@ static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out,
         hipError_t e = launch_mode<MAXD, MODE_COST>(sc, fr, out, ray_count, qs, (fr.n_chunks + 63u) / 64u, stream, use_lds);
         if (e != hipSuccess) return e;
         return launch_main<MAXD, MODE_STATIC>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
+    }
+    if ((variant & RT_VARIANT_COOP) != 0 && !use_lds) {
+        const uint32_t groups = (fr.n_chunks + COOP_WAVES - 1u) / COOP_WAVES;
+        if (groups == 0u) return hipSuccess;
+        if (g_ev_start) (void)hipEventRecord(g_ev_start, stream);
+        hipLaunchKernelGGL((whitted_coop_kernel<MAXD>), dim3(groups), dim3(COOP_WAVES * 64), COOP_LDS_BYTES, stream, sc, fr, out, ray_count, qs);
+        if (g_ev_stop) (void)hipEventRecord(g_ev_stop, stream);
+        return hipGetLastError();
     }
     if (scheme == RT_VARIANT_PERSISTENT) {
         const uint32_t waves = fr.n_chunks < resident_waves ? fr.n_chunks : resident_waves;

@@ -237,6 +237,8 @@ int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d
  *             2: one 8x8 tile per wave, dispatched in image order (default)
  *             4: persistent waves, lanes refill pixel by pixel from a work queue
  *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
+ *   bit 3     8: cooperative workgroups: 256-thread groups of four tiles whose four waves split every live
+ *                tile's triangle loop (finished waves help the others); bits 1-2 are then ignored
  * Default 2, or the value of the RT_AMD_VARIANT environment variable at load. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);

@@ -43,7 +43,7 @@ def _compare(world, camera, scene, frame, variant=0):
     return got, casts
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
 @pytest.mark.parametrize("w,h,depth", [(256, 256, 1), (320, 240, 5), (200, 150, 8), (97, 61, 0), (64, 64, 3)])
 def test_whitted_bit_exact(ctx, w, h, depth, variant):
     world, camera, scene = ctx

@@ -50,5 +50,9 @@ for k in (1, 2, 3, 4, 5, 8, 12, 20, 30, 40, 50):
     m = it == k
     if m.any():
         print(f"  iterations={k:3d}: waves={m.sum():6d} mean dur {dur[m].mean():8.1f} us  ({dur[m].mean() / k:6.1f} us/iter)")
+for lo, hi in ((1, 9), (9, 21), (21, 100)):
+    m = (it >= lo) & (it < hi)
+    if m.any():
+        print(f"  waves with {lo}..{hi - 1} trips: cast {cast_cyc[m].sum() / it[m].sum():.0f} cycles/trip, rest {(wave_cyc[m].sum() - cast_cyc[m].sum()) / it[m].sum():.0f} cycles/trip")
 print(f"  share of wave cycles inside cast(): {cast_cyc.sum() / wave_cyc.sum():.3f}  (mean cast {cast_cyc.sum() / it.sum():.0f} cycles/iteration, wave {wave_cyc.sum() / it.sum():.0f} cycles/iteration)")
 np.save("gpurun_out/timeline.npy", t)
