@@ -496,7 +496,22 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.samples = d_samples;
     dp.valid = d_valid;
     dp.ray_count = d_ray_count;
-    hipError_t e = rt::launch_distributed(scene->ks, kf, dp, static_cast<hipStream_t>(hip_stream));
+    dp.work_queue = nullptr;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    uint32_t dist_waves = scene->resident_waves;
+    {
+        const char *v = getenv("RT_AMD_DIST_STATIC"); /* A/B: one 64-pixel chunk per wave instead of persistent lanes */
+        if (!(v && *v == '1')) {
+            rt_scene *mut = const_cast<rt_scene *>(scene);
+            std::lock_guard<std::mutex> lock(mut->ws_mutex);
+            Workspace &ws = mut->workspaces[stream];
+            if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
+            dp.work_queue = ws.d_counters;
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (dp.work_queue) e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = rt::launch_distributed(scene->ks, kf, dp, dist_waves, stream);
     if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
     return RT_OK;
 }

@@ -174,29 +174,31 @@ struct DFrame {
     uint32_t kind;   /* 0 Diffuse, 1 Reflection, 2 Refraction */
 };
 
+#ifndef RT_DIST_MIN_WAVES
+#define RT_DIST_MIN_WAVES 3 /* waves per SIMD the register allocation aims for (profiles/README.md) */
+#endif
 template <int MAXD>
-__global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
+__global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t total_slots = fr.cols * fr.rows;
     const uint32_t band_slots = fr.cols << 3;
-    const uint32_t slot = wave * 64u + lane;
-    const bool in_image = slot < total_slots;
-    /* same slot -> pixel mapping as the Whitted kernel: 8-row bands, column-major inside a band */
+    /* Persistent lanes: a lane takes a pixel, runs ALL of this call's epochs for it (the pixel's random stream
+     * is sequential), then takes the next pixel.  The scattered rays are incoherent whatever the assignment, so
+     * nothing is lost by mixing pixels in a wave, and every lane stays busy until the tile runs dry.  Pixels are
+     * handed out as in the Whitted kernel: 64-slot chunks from a global counter (one atomic per chunk per wave),
+     * slots inside a chunk by ballot + prefix count.  dp.work_queue == nullptr selects the static assignment
+     * (wave w = chunk w), kept for A/B. */
+    const bool persistent = dp.work_queue != nullptr;
+    uint32_t q_next = 0u, q_end = 0u;
+    bool exhausted = false;
+    if (!persistent) {
+        q_next = wave * 64u < total_slots ? wave * 64u : total_slots;
+        q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
+        exhausted = true;
+    }
     uint32_t out_index = 0u;
     float clip_x = 0.0f, clip_y = 0.0f;
-    if (in_image) {
-        const uint32_t band = slot / band_slots;
-        const uint32_t r = slot - band * band_slots;
-        const uint32_t rows_left = fr.rows - (band << 3);
-        const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
-        const uint32_t col = r / band_rows;
-        const uint32_t row = (band << 3) + (r - col * band_rows);
-        out_index = row * fr.cols + col;
-        const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
-        clip_y = (fr.half_height - (float)y) / fr.height_f; /* main.rs:1134-1135 */
-        clip_x = ((float)x - fr.half_width) / fr.height_f;
-    }
     const V3 cam_x = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
     const V3 cam_y = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
     const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
     const size_t n_pixels = total_slots;
 
     Rng rng;
-    rng.st = dp.rng_states + (size_t)(in_image ? out_index : 0u) * RNG_WORDS;
-    rng.index = in_image ? rng.st[RNG_INDEX] : 256u;
+    rng.st = dp.rng_states;
+    rng.index = 256u;
 
     uint32_t phase = DP_DONE;
     uint32_t epoch = 0u;
@@ -248,12 +250,48 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
         phase = DP_PRIMARY;
     };
 
-    if (in_image && dp.n_epochs > 0u) {
-        if (dp.accum != nullptr) accum = v3(dp.accum[(size_t)out_index * 3u], dp.accum[(size_t)out_index * 3u + 1u], dp.accum[(size_t)out_index * 3u + 2u]);
-        start_epoch();
-    }
+    for (;;) {
+        /* ---- idle lanes take the next pixels ---- */
+        unsigned long long need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
+        if (dp.n_epochs == 0u) need = 0ull;
+        while (need != 0ull) {
+            if (q_next == q_end) { /* wave-uniform */
+                if (exhausted) break;
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(dp.work_queue, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c * 64u >= total_slots) { exhausted = true; break; }
+                q_next = c * 64u;
+                q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t avail = q_end - q_next;
+            if (phase == DP_DONE && rank < avail) {
+                /* same slot -> pixel mapping as the Whitted kernel: 8-row bands, column-major inside a band */
+                const uint32_t slot = q_next + rank;
+                const uint32_t band = slot / band_slots;
+                const uint32_t r = slot - band * band_slots;
+                const uint32_t rows_left = fr.rows - (band << 3);
+                const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
+                const uint32_t col = r / band_rows;
+                const uint32_t row = (band << 3) + (r - col * band_rows);
+                out_index = row * fr.cols + col;
+                const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+                clip_y = (fr.half_height - (float)y) / fr.height_f; /* main.rs:1134-1135 */
+                clip_x = ((float)x - fr.half_width) / fr.height_f;
+                rng.st = dp.rng_states + (size_t)out_index * RNG_WORDS;
+                rng.index = rng.st[RNG_INDEX];
+                accum = v3(0.0f, 0.0f, 0.0f);
+                if (dp.accum != nullptr) accum = v3(dp.accum[(size_t)out_index * 3u], dp.accum[(size_t)out_index * 3u + 1u], dp.accum[(size_t)out_index * 3u + 2u]);
+                epoch = 0u;
+                start_epoch();
+            }
+            const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+            q_next += n_need < avail ? n_need : avail;
+            need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
+        }
+        if (__builtin_amdgcn_ballot_w64(phase != DP_DONE) == 0ull) break;
 
-    while (__builtin_amdgcn_ballot_w64(phase != DP_DONE) != 0ull) {
         CastResult cr;
         cr.prim = -1;
         cr.t = 0.0f;
@@ -496,7 +534,12 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
                 epoch += 1u;
                 if (epoch < dp.n_epochs) {
                     start_epoch();
-                } else {
+                } else { /* this pixel is finished for this call: park its stream position and its sum */
+                    rng.st[RNG_INDEX] = rng.index;
+                    if (dp.accum != nullptr) {
+                        float *o = dp.accum + (size_t)out_index * 3u;
+                        o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
+                    }
                     phase = DP_DONE;
                 }
                 break;
@@ -504,13 +547,6 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
         }
     }
 
-    if (in_image) {
-        rng.st[RNG_INDEX] = rng.index;
-        if (dp.accum != nullptr && dp.n_epochs > 0u) {
-            float *o = dp.accum + (size_t)out_index * 3u;
-            o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
-        }
-    }
     if (dp.ray_count != nullptr) {
         uint32_t c = casts;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
@@ -518,10 +554,11 @@ __global__ __launch_bounds__(64, 4) void distributed_kernel(const KernelScene sc
     }
 }
 
-hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream) {
+hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
     const uint32_t total = fr.cols * fr.rows;
-    const uint32_t waves = (total + 63u) / 64u;
+    uint32_t waves = (total + 63u) / 64u;
     if (waves == 0u) return hipSuccess;
+    if (dp.work_queue != nullptr && waves > resident_waves) waves = resident_waves; /* persistent lanes: fill the chip once */
     if (fr.max_depth <= 8) {
         hipLaunchKernelGGL((distributed_kernel<9>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     } else {

@@ -95,10 +95,11 @@ struct DistParams {
     float *samples;                /* n_epochs*pixels*3 raw samples; may be null */
     unsigned char *valid;          /* n_epochs*pixels filter flags; may be null */
     unsigned long long *ray_count; /* may be null */
+    uint32_t *work_queue;          /* zeroed chunk counter: persistent lanes; null: one chunk per wave */
 };
 #define RT_RNG_STATE_WORDS 516u
 hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t stream);
-hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream);
+hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
 
 /* post_process / sRGB encode on the device (rt_post.hip) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,

@@ -27,8 +27,15 @@ ap.add_argument("--epochs", type=int, default=8)
 ap.add_argument("--calls", type=int, default=3)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
+ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
+if a.lib:
+    import ctypes as C
+    from homework_18_graphics_raytracer_amd import _capi
+    _capi._amd = None
+    _orig = _capi._load
+    _capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / f"librt_amd_{a.lib}.so")) if name == "librt_amd.so" else _orig(name)
 world = rt.reference_world()
 cam = rt.reference_camera()
 scene = rt.Scene(world)
