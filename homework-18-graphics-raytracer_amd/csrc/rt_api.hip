@@ -182,7 +182,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     using rt::V3;
     std::vector<rt::DevTri> tris(desc->n_triangles);
     std::vector<rt::DevTriAttr> attrs(desc->n_triangles);
-    std::vector<rt::DevTriHot> hot(desc->n_triangles);
     for (uint32_t i = 0; i < desc->n_triangles; ++i) {
         const rt_triangle &s = desc->triangles[i];
         rt::DevTri &t = tris[i];
@@ -203,11 +202,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
         t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
         t.area = rt::dot(rt::cross(v1 - v0, v2 - v0), n); /* main.rs:235 */
-        rt::DevTriHot &h = hot[i];
-        memset(&h, 0, sizeof h);
-        memcpy(h.n, t.n, sizeof h.n); h.d = t.d;
-        memcpy(h.v0, t.v0, sizeof h.v0); memcpy(h.v1, t.v1, sizeof h.v1); memcpy(h.v2, t.v2, sizeof h.v2);
-        memcpy(h.e0, t.e0, sizeof h.e0); memcpy(h.e1, t.e1, sizeof h.e1); memcpy(h.e2, t.e2, sizeof h.e2);
         for (int k = 0; k < 3; ++k) {
             a.n0[k] = s.vertices[0].normal[k];
             a.n1[k] = s.vertices[1].normal[k];
@@ -231,8 +225,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t off_tris = 0;
     const size_t off_attrs = off_tris + up(tris.size() * sizeof(rt::DevTri));
-    const size_t off_hot = off_attrs + up(attrs.size() * sizeof(rt::DevTriAttr));
-    const size_t off_spheres = off_hot + up(hot.size() * sizeof(rt::DevTriHot));
+    const size_t off_spheres = off_attrs + up(attrs.size() * sizeof(rt::DevTriAttr));
     const size_t off_mats = off_spheres + up(spheres.size() * sizeof(rt::DevSphere));
     const size_t off_lights = off_mats + up(desc->n_materials * sizeof(rt_material));
     const size_t total = off_lights + up(desc->n_lights * sizeof(rt_light)) + 256;
@@ -240,7 +233,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     std::vector<unsigned char> blob(total, 0);
     if (!tris.empty()) memcpy(&blob[off_tris], tris.data(), tris.size() * sizeof(rt::DevTri));
     if (!attrs.empty()) memcpy(&blob[off_attrs], attrs.data(), attrs.size() * sizeof(rt::DevTriAttr));
-    if (!hot.empty()) memcpy(&blob[off_hot], hot.data(), hot.size() * sizeof(rt::DevTriHot));
     if (!spheres.empty()) memcpy(&blob[off_spheres], spheres.data(), spheres.size() * sizeof(rt::DevSphere));
     if (desc->n_materials) memcpy(&blob[off_mats], desc->materials, desc->n_materials * sizeof(rt_material));
     if (desc->n_lights) memcpy(&blob[off_lights], desc->lights, desc->n_lights * sizeof(rt_light));
@@ -259,7 +251,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     unsigned char *base = static_cast<unsigned char *>(sc->d_blob);
     sc->ks.tris = reinterpret_cast<const rt::DevTri *>(base + off_tris);
     sc->ks.attrs = reinterpret_cast<const rt::DevTriAttr *>(base + off_attrs);
-    sc->ks.hot = reinterpret_cast<const rt::DevTriHot *>(base + off_hot);
     sc->ks.spheres = reinterpret_cast<const rt::DevSphere *>(base + off_spheres);
     sc->ks.materials = reinterpret_cast<const rt_material *>(base + off_mats);
     sc->ks.lights = reinterpret_cast<const rt_light *>(base + off_lights);

@@ -12,10 +12,10 @@
  *   area = ((v1-v0) x (v2-v0)) . n           main.rs:235
  *   r2  = radius * radius                    main.rs:272 (powi(2))
  *
- * DevTri is 96 bytes = three 32-byte groups; the intersection loop indexes it
- * with a wave-uniform index, so the compiler fetches it with scalar loads
- * (s_load_dwordx8) into SGPRs, or the kernel stages it in LDS (see
- * rt_kernels.hip) — either way one fetch serves all 64 lanes.
+ * DevTri is 128 bytes; the intersection loop indexes it with a wave-uniform index
+ * and fetches its first 112 bytes with scalar loads (s_load_dwordx16 + x8 + x4)
+ * into SGPRs (rt_cast_asm.h), or the kernel stages it in LDS (variant bit 0) —
+ * either way one fetch serves all 64 lanes.
  */
 #ifndef RT_DEVICE_SCENE_H
 #define RT_DEVICE_SCENE_H
@@ -35,17 +35,6 @@ struct alignas(32) DevTri {
     float pad4[4];
 };
 static_assert(sizeof(DevTri) == 128, "DevTri must be 128 bytes");
-
-/* The 22 floats the intersection loop reads per triangle, packed to 96 bytes so that one triangle is
- * three s_load_dwordx8 (or x16 + x8) into 24 SGPRs; two of these fit the SGPR file, which is what
- * lets the loop fetch triangle i+1 while it tests triangle i (rt_kernels.hip, cast_sgpr). */
-struct alignas(32) DevTriHot {
-    float n[3]; float d;
-    float v0[3]; float v1[3]; float v2[3];
-    float e0[3]; float e1[3]; float e2[3];
-    float pad[2];
-};
-static_assert(sizeof(DevTriHot) == 96, "DevTriHot must be 96 bytes");
 
 /* per-vertex attributes, only read for the winning primitive of a cast */
 struct alignas(16) DevTriAttr {

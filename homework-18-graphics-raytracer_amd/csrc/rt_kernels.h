@@ -42,7 +42,6 @@ namespace rt {
 /* device pointers + counts, passed by value as kernel arguments (lands in SGPRs) */
 struct KernelScene {
     const DevTri *tris;
-    const DevTriHot *hot;
     const DevTriAttr *attrs;
     const DevSphere *spheres;
     const rt_material *materials;

@@ -40,250 +40,6 @@
 
 namespace rt {
 
-/* ---- cast, software-pipelined form ------------------------------------------------
- * Same arithmetic as cast<> above, restructured for the machine:
- *   - the 22 floats of a triangle arrive as ONE bulk scalar fetch (DevTriHot, 96 B);
- *   - triangle i+1 is fetched while triangle i is tested (two SGPR buffers A/B; the
- *     sched_barriers pin "wait for this buffer -> issue the next fetch -> compute",
- *     because scalar loads return out of order and any wait is a wait for all);
- *   - the per-lane accept predicate is carried as a mask and applied with selects
- *     instead of nested exec regions; two wave ballots skip the rest of a triangle
- *     when no lane is still alive (after culling/exclusion, and after t <= 0).
- * Lanes that are not alive still execute the arithmetic; their results are discarded.
- */
-struct TriAccum {
-    float t;
-    int32_t prim;
-    uint32_t bf;
-    float a0, a1, a2;
-    bool have;
-};
-
-struct RayCtx {
-    V3 o, d;
-    bool cull_back, cull_front, ex_some;
-    uint32_t ex_prim, ex_face;
-};
-
-__device__ __forceinline__ void test_triangle(const DevTriHot &T, uint32_t i, const RayCtx &r, float nd, TriAccum &best) {
-    const V3 n = v3(T.n[0], T.n[1], T.n[2]);
-    const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
-    bool alive = !(bf ? r.cull_back : r.cull_front); /* main.rs:185-188 */
-    {
-        const bool criteria = r.ex_face == FACE_FRONT ? !bf : (r.ex_face == FACE_BACK ? bf : true);
-        alive = alive && !(r.ex_some && r.ex_prim == i && criteria); /* main.rs:190-200 */
-    }
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-    const float t = (T.d - dot(n, r.o)) / nd; /* main.rs:203-204 */
-    alive = alive && !(t <= 0.0f);               /* NaN passes, as in the reference */
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-    const V3 p = r.o + r.d * t;
-    const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
-    const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
-    const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
-    alive = alive && !(a0 < 0.0f || a1 < 0.0f || a2 < 0.0f); /* NaN areas pass (main.rs:224) */
-    alive = alive && !(best.have && best.t < t);             /* ties: the later primitive wins */
-    best.have = best.have || alive;
-    best.t = alive ? t : best.t;
-    best.prim = alive ? (int32_t)i : best.prim;
-    best.bf = alive ? (bf ? 1u : 0u) : best.bf;
-    best.a0 = alive ? a0 : best.a0;
-    best.a1 = alive ? a1 : best.a1;
-    best.a2 = alive ? a2 : best.a2;
-}
-
-typedef const float __attribute__((address_space(4))) *ConstF;
-
-/* one triangle record = 24 consecutive dwords, fetched through the constant address space */
-__device__ __forceinline__ DevTriHot load_hot(ConstF base, uint32_t i) {
-    const ConstF p = base + (size_t)i * (sizeof(DevTriHot) / sizeof(float));
-    DevTriHot h;
-    float *f = reinterpret_cast<float *>(&h);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(DevTriHot) / sizeof(float)); ++k) f[k] = p[k];
-    return h;
-}
-
-__device__ __forceinline__ CastResult cast_pipelined(const KernelScene &sc, const Ray &ray) {
-    TriAccum best;
-    best.prim = -1;
-    best.t = 0.0f;
-    best.bf = 0u;
-    best.a0 = best.a1 = best.a2 = 0.0f;
-    best.have = false;
-    RayCtx r;
-    r.o = ray.o;
-    r.d = ray.d;
-    r.cull_back = ray.mode == FACE_FRONT;
-    r.cull_front = ray.mode == FACE_BACK;
-    r.ex_some = (ray.excl >> 31) != 0u;
-    r.ex_prim = ray.excl & 0x1fffffffu;
-    r.ex_face = (ray.excl >> 29) & 3u;
-
-    const uint32_t nt = sc.n_triangles;
-    /* constant address space (4): the scene is immutable for the lifetime of the launch, which is what
-     * lets the compiler keep these wave-uniform fetches on the scalar unit (s_load) next to the sched_barriers */
-    const ConstF hot = (ConstF)(uintptr_t)sc.hot;
-    if (nt != 0u) {
-        DevTriHot A = load_hot(hot, 0u);
-        for (uint32_t i = 0; i < nt; i += 2u) {
-            /* first use of A: forces the wait for A's fetch */
-            const float ndA = dot(v3(A.n[0], A.n[1], A.n[2]), r.d);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t ib = (i + 1u < nt) ? i + 1u : i;
-            DevTriHot B = load_hot(hot, ib); /* in flight while A is tested */
-            __builtin_amdgcn_sched_barrier(0);
-            test_triangle(A, i, r, ndA, best);
-            __builtin_amdgcn_sched_barrier(0);
-            const float ndB = dot(v3(B.n[0], B.n[1], B.n[2]), r.d);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t ia = (i + 2u < nt) ? i + 2u : i;
-            A = load_hot(hot, ia); /* in flight while B is tested */
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1u < nt) test_triangle(B, i + 1u, r, ndB, best);
-        }
-    }
-
-    const uint32_t ns = sc.n_spheres;
-    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
-        const DevSphere &S = sc.spheres[i];
-        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
-        const V3 disp = c - r.o;
-        const float lsd = magnitude(cross(disp, r.d));
-        bool alive = !(lsd > S.radius);
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
-        const float tc = dot(r.d, disp);
-        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
-        const bool both_back = tc < k;
-        const bool bf = ray.mode == FACE_BACK || (ray.mode == FACE_BOTH && both_back);
-        const float t = bf ? tc + k : tc - k;
-        alive = alive && !(t <= 0.0f);
-        {
-            const bool criteria = r.ex_face == FACE_FRONT ? !bf : (r.ex_face == FACE_BACK ? bf : true);
-            alive = alive && !(r.ex_some && r.ex_prim == nt + i && criteria);
-        }
-        alive = alive && !(best.have && best.t < t);
-        best.have = best.have || alive;
-        best.t = alive ? t : best.t;
-        best.prim = alive ? (int32_t)(nt + i) : best.prim;
-        best.bf = alive ? (bf ? 1u : 0u) : best.bf;
-    }
-    CastResult out;
-    out.t = best.t;
-    out.prim = best.prim;
-    out.bf = best.bf;
-    out.a0 = best.a0; out.a1 = best.a1; out.a2 = best.a2;
-    return out;
-}
-
-/* cast, bulk-fetch form: the control flow of cast<> (nested early-outs), but each triangle's 22 floats
- * arrive as one 96-byte scalar fetch through the constant address space, RT_CAST_UNROLL triangles per
- * wait, instead of three dependent fetches per triangle. */
-#ifndef RT_CAST_UNROLL
-#define RT_CAST_UNROLL 2
-#endif
-__device__ __forceinline__ CastResult cast_bulk(const KernelScene &sc, const Ray &ray) {
-    CastResult best;
-    best.prim = -1;
-    best.t = 0.0f;
-    best.bf = 0u;
-    best.a0 = best.a1 = best.a2 = 0.0f;
-    bool have = false;
-    const bool cull_back = ray.mode == FACE_FRONT;
-    const bool cull_front = ray.mode == FACE_BACK;
-    const bool ex_some = (ray.excl >> 31) != 0u;
-    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
-    const uint32_t ex_face = (ray.excl >> 29) & 3u;
-    const uint32_t nt = sc.n_triangles;
-    const ConstF hot = (ConstF)(uintptr_t)sc.hot;
-    for (uint32_t base = 0; base < nt; base += RT_CAST_UNROLL) {
-        DevTriHot Ts[RT_CAST_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RT_CAST_UNROLL; ++u) Ts[u] = load_hot(hot, (base + u < nt) ? base + u : nt - 1u);
-#pragma unroll
-        for (int u = 0; u < RT_CAST_UNROLL; ++u) {
-            const uint32_t i = base + (uint32_t)u;
-            if (i >= nt) break;
-            const DevTriHot &T = Ts[u];
-            const V3 n = v3(T.n[0], T.n[1], T.n[2]);
-            const float nd = dot(n, ray.d);
-            const bool bf = nd > 0.0f;
-            if (bf ? cull_back : cull_front) continue;
-            if (ex_some && ex_prim == i) {
-                const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
-                if (criteria) continue;
-            }
-            const float t = (T.d - dot(n, ray.o)) / nd;
-            if (t <= 0.0f) continue;
-            const V3 p = ray.o + ray.d * t;
-            const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
-            const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
-            const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
-            if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue;
-            if (have && best.t < t) continue;
-            have = true;
-            best.t = t;
-            best.prim = (int32_t)i;
-            best.bf = bf ? 1u : 0u;
-            best.a0 = a0; best.a1 = a1; best.a2 = a2;
-        }
-    }
-    const uint32_t ns = sc.n_spheres;
-    for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
-        const DevSphere &S = sc.spheres[i];
-        const V3 c = v3(S.c[0], S.c[1], S.c[2]);
-        const V3 disp = c - ray.o;
-        const float lsd = magnitude(cross(disp, ray.d));
-        if (lsd > S.radius) continue;
-        const float tc = dot(ray.d, disp);
-        const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);
-        float t;
-        bool bf;
-        if (ray.mode == FACE_FRONT) { t = tc - k; bf = false; }
-        else if (ray.mode == FACE_BACK) { t = tc + k; bf = true; }
-        else if (tc < k) { t = tc + k; bf = true; }
-        else { t = tc - k; bf = false; }
-        if (t <= 0.0f) continue;
-        if (ex_some && ex_prim == nt + i) {
-            const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
-            if (criteria) continue;
-        }
-        if (have && best.t < t) continue;
-        have = true;
-        best.t = t;
-        best.prim = (int32_t)(nt + i);
-        best.bf = bf ? 1u : 0u;
-    }
-    return best;
-}
-
-/* Out-of-line instance of the scalar-fetch cast.  Keeping the intersection loop in its own function gives it
- * its own register allocation: the surrounding state machine (and whatever is added to it) can no longer push
- * spills or extra live ranges into the loop that does 95 % of the work. */
-#ifdef RT_CAST_OUTLINED /* experiment: measured 1.5x slower — function arguments arrive in VGPRs, so the triangle fetches stop being scalar */
-__device__ __attribute__((noinline)) CastResult cast_outlined(const DevTri *tris, uint32_t n_triangles, const DevSphere *spheres,
-                                                              uint32_t n_spheres, float ox, float oy, float oz, float dx, float dy,
-                                                              float dz, uint32_t mode, uint32_t excl) {
-    KernelScene sc;
-    sc.tris = tris;
-    sc.attrs = nullptr;
-    sc.hot = nullptr;
-    sc.spheres = spheres;
-    sc.materials = nullptr;
-    sc.lights = nullptr;
-    sc.n_triangles = n_triangles;
-    sc.n_spheres = n_spheres;
-    sc.n_materials = 0u;
-    sc.n_lights = 0u;
-    Ray r;
-    r.o = v3(ox, oy, oz);
-    r.d = v3(dx, dy, dz);
-    r.mode = mode;
-    r.excl = excl;
-    return cast<false>(sc, nullptr, r);
-}
-#endif
-
 /* ---- the per-lane state machine ---------------------------------------------- */
 
 enum : uint32_t {
@@ -630,15 +386,7 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
         const unsigned long long diag_ca = __builtin_amdgcn_s_memtime();
 #endif
         if (phase != PH_DONE) {
-#ifdef RT_CAST_PIPELINED /* experiment: compiler-generated SGPR double buffering; slower than the plain loop (profiles/README) */
-            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_pipelined(sc, req);
-#elif defined(RT_CAST_BULK)
-            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_bulk(sc, req);
-#elif defined(RT_CAST_OUTLINED)
-            cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req)
-                         : cast_outlined(sc.tris, sc.n_triangles, sc.spheres, sc.n_spheres, req.o.x, req.o.y, req.o.z, req.d.x, req.d.y,
-                                         req.d.z, req.mode, req.excl);
-#elif defined(RT_CAST_COMPILER) /* the compiler-generated loop (round-1 v1..v3) */
+#ifdef RT_CAST_COMPILER /* the compiler-generated loop of the first builds, for A/B */
             cr = cast<USE_LDS>(sc, lds_tris, req);
 #else
             if (MODE != MODE_COOP) cr = USE_LDS ? cast<USE_LDS>(sc, lds_tris, req) : cast_asm(sc, req);
