@@ -123,7 +123,7 @@ class Frame(C.Structure):
 AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
-    "rt_get_variant", "rt_set_eviction", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
+    "rt_get_variant", "rt_set_eviction", "rt_set_wavefront_budget", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
     "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_post_process_device", "rt_encode_srgb8_device",
 ]
 HOST_SYMBOLS = [
@@ -206,6 +206,7 @@ def amd_lib() -> C.CDLL:
         lib.rt_render_distributed.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_float, C.c_float, C.c_void_p,
                                               C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_set_eviction.argtypes = [C.c_int, C.c_int]
+        lib.rt_set_wavefront_budget.argtypes = [C.c_uint]
         lib.rt_profile_enable.argtypes = [C.c_int]
         lib.rt_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint)]
         lib.rt_math_eval_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

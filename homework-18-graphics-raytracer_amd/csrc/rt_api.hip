@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <new>
@@ -38,6 +40,10 @@ struct Workspace {
     size_t cont_bytes = 0;
     uint32_t *d_tiles = nullptr; /* RT_PROBE_CLASSES lists of tiles_n chunk ids */
     size_t tiles_n = 0;
+    void *d_pwf = nullptr; /* persistent-wavefront path: global words + one arena per workgroup */
+    size_t pwf_bytes = 0;
+    void *d_wf = nullptr; /* wavefront path: counters + node inputs + node records + shade tasks + refraction tasks */
+    size_t wf_capacity = 0;
 };
 
 struct rt_scene {
@@ -45,11 +51,14 @@ struct rt_scene {
     void *d_blob; /* one allocation holding every array */
     rt::KernelScene ks;
     uint32_t resident_waves; /* CUs * 4 SIMDs * RT_MIN_WAVES: the persistent grid */
+    uint32_t pwf_workgroups;  /* CUs * resident workgroups of the persistent-wavefront kernel */
+    uint32_t wavefront_waves; /* CUs * 4 SIMDs * 8: the wavefront kernels' persistent grid (the hardware limit of resident waves) */
     std::mutex ws_mutex;
     std::map<hipStream_t, Workspace> workspaces;
 };
 
 static int g_evict_threshold = -1, g_evict_min_iter = -1;
+static int g_wf_nodes_per_pixel = -1;
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
@@ -112,6 +121,12 @@ int rt_set_variant(int variant) {
     return RT_OK;
 }
 int rt_get_variant(void) { return current_variant(); }
+
+int rt_set_wavefront_budget(unsigned nodes_per_pixel) {
+    if (nodes_per_pixel < 1u || nodes_per_pixel > 4096u) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_wavefront_budget: 1..4096 nodes per pixel");
+    g_wf_nodes_per_pixel = (int)nodes_per_pixel;
+    return RT_OK;
+}
 
 /* ---- profiling of the dominant kernel ----
  * bench.py's roofline needs the duration of the render kernel alone (a call may also launch the small probe
@@ -211,6 +226,70 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         a.uv1x = s.vertices[1].uv[0]; a.uv1y = s.vertices[1].uv[1];
         a.uv2x = s.vertices[2].uv[0]; a.uv2y = s.vertices[2].uv[1];
     }
+    /* bounding spheres for the conservative rejection in the intersection loop (rt_device_scene.h) */
+    double scene_extent = 0.0;
+    for (uint32_t i = 0; i < desc->n_triangles; ++i)
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) {
+                const double a = fabs((double)desc->triangles[i].vertices[v].position[k]);
+                if (a > scene_extent) scene_extent = a; /* NaN never compares greater */
+            }
+    const bool filter_off = getenv("RT_AMD_NO_SPHERE_FILTER") != nullptr; /* A/B switch; results are the same either way */
+    const char *frac_env = getenv("RT_AMD_FILTER_MAX_FRAC");
+    /* a triangle as large as the scene rejects next to nothing: not worth its ten instructions */
+    const double max_frac = (frac_env && *frac_env) ? atof(frac_env) : 0.5;
+    for (uint32_t i = 0; i < desc->n_triangles; ++i) {
+        rt::DevTri &t = tris[i];
+        t.bq = std::numeric_limits<float>::infinity();
+        t.bcx = t.bcy = t.bcz = 0.0f;
+        double P[3][3];
+        bool finite = true;
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) {
+                P[v][k] = (double)desc->triangles[i].vertices[v].position[k];
+                finite = finite && std::isfinite(P[v][k]);
+            }
+        if (!finite || filter_off || !(scene_extent <= 1e10)) continue;
+        auto sub = [](const double *a, const double *b, double *o) { for (int k = 0; k < 3; ++k) o[k] = a[k] - b[k]; };
+        auto dotd = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        double ab[3], ac[3], bc[3];
+        sub(P[1], P[0], ab); sub(P[2], P[0], ac); sub(P[2], P[1], bc);
+        const double la = dotd(bc, bc), lb = dotd(ac, ac), lc = dotd(ab, ab); /* squared sides opposite A, B, C */
+        if (!(la > 0.0 && lb > 0.0 && lc > 0.0)) continue;
+        /* smallest angle, from sin and cos at each vertex */
+        double cr[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+        const double twice_area = sqrt(dotd(cr, cr));
+        const double angA = atan2(twice_area, dotd(ab, ac));
+        const double angB = atan2(twice_area, -dotd(ab, bc));
+        const double angC = atan2(twice_area, dotd(ac, bc));
+        const double ang_min = angA < angB ? (angA < angC ? angA : angC) : (angB < angC ? angB : angC);
+        if (!(ang_min >= 0.0201)) continue; /* sin(angle/2) >= 0.01 */
+        double c[3], r2;
+        if (la >= lb + lc) { for (int k = 0; k < 3; ++k) c[k] = 0.5 * (P[1][k] + P[2][k]); r2 = 0.25 * la; }
+        else if (lb >= la + lc) { for (int k = 0; k < 3; ++k) c[k] = 0.5 * (P[0][k] + P[2][k]); r2 = 0.25 * lb; }
+        else if (lc >= la + lb) { for (int k = 0; k < 3; ++k) c[k] = 0.5 * (P[0][k] + P[1][k]); r2 = 0.25 * lc; }
+        else { /* acute: circumcentre */
+            const double wa = la * (lb + lc - la), wb = lb * (lc + la - lb), wc = lc * (la + lb - lc);
+            const double w = wa + wb + wc;
+            for (int k = 0; k < 3; ++k) c[k] = (wa * P[0][k] + wb * P[1][k] + wc * P[2][k]) / w;
+            double d0[3];
+            sub(P[0], c, d0);
+            r2 = dotd(d0, d0);
+        }
+        /* the sphere must contain the three vertices whatever the rounding above did */
+        for (int v = 0; v < 3; ++v) {
+            double dv[3];
+            sub(P[v], c, dv);
+            const double q = dotd(dv, dv);
+            if (q > r2) r2 = q;
+        }
+        const double radius = sqrt(r2);
+        if (!(radius <= max_frac * scene_extent)) continue;
+        if (!(radius >= 1e-3 * scene_extent) || !std::isfinite(radius)) continue; /* tiny against the scene: p - c would cancel */
+        t.bcx = (float)c[0]; t.bcy = (float)c[1]; t.bcz = (float)c[2];
+        /* 1.05 R^2, plus the float rounding of the centre (<= 1e-7 * extent per axis, far inside the margin), rounded up */
+        t.bq = std::nextafter((float)(1.05 * r2 * 1.0001), std::numeric_limits<float>::infinity());
+    }
     std::vector<rt::DevSphere> spheres(desc->n_spheres);
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const rt_sphere &s = desc->spheres[i];
@@ -258,10 +337,13 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.n_spheres = desc->n_spheres;
     sc->ks.n_materials = desc->n_materials;
     sc->ks.n_lights = desc->n_lights;
+    sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
     if (e != hipSuccess || cus <= 0) cus = 256;
     sc->resident_waves = (uint32_t)cus * 4u * (uint32_t)RT_MIN_WAVES;
+    sc->wavefront_waves = (uint32_t)cus * 4u * 8u;
+    sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu();
     *out_scene = sc;
     return RT_OK;
 }
@@ -273,6 +355,8 @@ int rt_scene_destroy(rt_scene *scene) {
         if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
         if (kv.second.d_cont) (void)hipFree(kv.second.d_cont);
         if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+        if (kv.second.d_wf) (void)hipFree(kv.second.d_wf);
+        if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
     }
     if (scene->d_blob) e = hipFree(scene->d_blob);
     delete scene;
@@ -318,7 +402,23 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     int rc = make_kernel_frame(camera, frame, &kf);
     if (rc != RT_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const int variant = current_variant();
+    int variant = current_variant();
+    /* the wavefront path packs the ray's face mode next to a 27-bit primitive id */
+    /* ... and the persistent-wavefront path also the depth left, next to a 21-bit primitive id */
+    if ((variant & RT_VARIANT_PWF) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 21)) variant &= ~RT_VARIANT_PWF;
+    if ((variant & RT_VARIANT_PWF) && (scene->ks.n_lights >= (1u << 15) || scene->ks.n_materials >= (1u << 16))) variant &= ~RT_VARIANT_PWF;
+    if (variant & RT_VARIANT_PWF) variant &= ~RT_VARIANT_WAVEFRONT;
+    if ((variant & RT_VARIANT_WAVEFRONT) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 27)) variant &= ~RT_VARIANT_WAVEFRONT;
+    if (g_wf_nodes_per_pixel < 0) {
+        const char *v = getenv("RT_AMD_WF_NODES_PER_PIXEL");
+        g_wf_nodes_per_pixel = (v && *v) ? atoi(v) : 6; /* the reference scene needs 3.4 at depth 8 */
+        if (g_wf_nodes_per_pixel < 1 || g_wf_nodes_per_pixel > 4096) g_wf_nodes_per_pixel = 6;
+    }
+    rt::WfBuffers wb;
+    memset(&wb, 0, sizeof wb);
+    rt::PwParams pw;
+    memset(&pw, 0, sizeof pw);
+    uint32_t pw_groups = 0;
     if (g_evict_threshold < 0) {
         const char *v = getenv("RT_AMD_EVICT_THRESHOLD");
         g_evict_threshold = (v && *v) ? atoi(v) : 16;
@@ -361,6 +461,64 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             }
             qs.tile_order = ws.d_tiles;
         }
+        if (variant & RT_VARIANT_PWF) {
+            const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
+            const uint64_t tiles = (pixels + 63u) / 64u;
+            uint64_t groups = (tiles + 7u) / 8u; /* a workgroup fetches tiles eight at a time */
+            if (groups > scene->pwf_workgroups) groups = scene->pwf_workgroups;
+            if (groups < 1) groups = 1;
+            const uint64_t want = (pixels * (uint64_t)g_wf_nodes_per_pixel + groups - 1) / groups; /* nodes per arena */
+            uint64_t ring = 2048;
+            while (ring < want + 1024u && ring < (1ull << 30)) ring <<= 1;
+            pw.ring_cap = (uint32_t)ring;
+            pw.node_cap = (uint32_t)(ring - 1024u);
+            /* (the budget sizes the rings; an arena may use all of its ring's worth of nodes: tiles are handed out
+             * dynamically, and a workgroup that met expensive ones needs more than the average) */
+            pw.tile_reserve = 10;
+            {   /* a stride near the golden section of the tile count scatters consecutive fetches over the image */
+                auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+                uint64_t stride = (uint64_t)((double)tiles * 0.6180339887498949);
+                if (stride < 1) stride = 1;
+                while (gcd(stride, tiles) != 1) stride += 1;
+                pw.tile_stride = (uint32_t)stride;
+            }
+            pw.arena_stride = (rt::pwf_arena_bytes(pw.node_cap, pw.ring_cap) + 255u) & ~(size_t)255u;
+            const size_t need = 256 + (size_t)groups * pw.arena_stride;
+            if (need > ws.pwf_bytes) {
+                if (ws.d_pwf) (void)hipFree(ws.d_pwf);
+                ws.d_pwf = nullptr;
+                ws.pwf_bytes = 0;
+                RT_HIP(hipMalloc(&ws.d_pwf, need));
+                ws.pwf_bytes = need;
+            }
+            pw.global = static_cast<uint32_t *>(ws.d_pwf);
+            pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 256;
+            pw_groups = (uint32_t)groups;
+        }
+        if (variant & RT_VARIANT_WAVEFRONT) {
+            const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
+            uint64_t capacity = pixels * (uint64_t)g_wf_nodes_per_pixel;
+            if (capacity > 0x7fffffffull) capacity = 0x7fffffffull;
+            if (capacity < pixels) {
+                variant &= ~RT_VARIANT_WAVEFRONT; /* tile too large for 32-bit node ids: per-pixel path */
+            } else {
+                const size_t per_node = (2 + 2 + 4 + 3) * sizeof(uint4);
+                if (capacity > ws.wf_capacity) {
+                    if (ws.d_wf) (void)hipFree(ws.d_wf);
+                    ws.d_wf = nullptr;
+                    ws.wf_capacity = 0;
+                    RT_HIP(hipMalloc(&ws.d_wf, 1024 + (size_t)capacity * per_node));
+                    ws.wf_capacity = (size_t)capacity;
+                }
+                unsigned char *p = static_cast<unsigned char *>(ws.d_wf);
+                wb.counters = reinterpret_cast<uint32_t *>(p);
+                wb.node_in = reinterpret_cast<uint4 *>(p + 1024);
+                wb.nodes = wb.node_in + (size_t)ws.wf_capacity * 2;
+                wb.shade = wb.nodes + (size_t)ws.wf_capacity * 2;
+                wb.refr = wb.shade + (size_t)ws.wf_capacity * 4;
+                wb.capacity = (uint32_t)capacity; /* the budget asked for, even when the allocation is larger */
+            }
+        }
         qs.work_queue = ws.d_counters;
         qs.cont_count = ws.d_counters + 1;
         qs.class_count = ws.d_counters + 2;
@@ -379,6 +537,18 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         g_prof_used += 1;
     }
     hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
+    if (e == hipSuccess && (variant & RT_VARIANT_PWF)) {
+        e = rt::launch_pwf(scene->ks, kf, d_rgb, d_ray_count, pw, pw_groups, stream);
+        /* a frame that did not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
+        qs.run_if = pw.global + PW_G_OVERFLOW;
+        variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;
+    }
+    if (e == hipSuccess && (variant & RT_VARIANT_WAVEFRONT)) {
+        e = rt::launch_wavefront(scene->ks, kf, d_rgb, d_ray_count, wb, scene->wavefront_waves, stream);
+        /* a frame that outgrew the node budget is rendered by the per-pixel kernel instead (a no-op otherwise) */
+        qs.run_if = wb.counters + WF_C_OVERFLOW;
+        variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;
+    }
     if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
     return RT_OK;

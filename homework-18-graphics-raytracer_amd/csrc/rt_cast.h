@@ -118,12 +118,25 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
  * which is exactly the reference's Option::None case).  The signed areas and the backface flag of the winner
  * are pure functions of (ray, triangle, t) and are re-evaluated once after the loop with the same operations;
  * the sphere loop (main.rs:264-324) stays in C++. */
+#ifdef RT_DIAG_STAGES /* diagnostic build: python tools/gen_cast_asm.py --count-stages > csrc/rt_cast_asm_diag.h */
+#include "rt_cast_asm_diag.h"
+#define RT_STAGE_OPERANDS , "+v"(stage_counts[0]), "+v"(stage_counts[1]), "+v"(stage_counts[2]), "+v"(stage_counts[3]), "+v"(stage_counts[4]), "+v"(stage_counts[5]), "+v"(stage_counts[6]), "+v"(stage_counts[7])
+static __device__ unsigned long long g_stage_totals[8]; /* per translation unit; read with RT_DIAG_STAGE_READER(name) */
+#define RT_DIAG_STAGE_READER(name)                                                                              \
+    extern "C" int name(unsigned long long *out8, int reset) {                                                  \
+        if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_stage_totals), 8 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_stage_totals), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }
+#else
 #include "rt_cast_asm.h"
+#define RT_STAGE_OPERANDS
+#endif
 
 /* The asm part over the triangle range [index_base, index_base + n): returns the range's nearest accepted hit
  * under the reference's sequential rule, as (best_t, best_prim) with best_prim a GLOBAL triangle index or -1. */
 __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uint32_t n, uint32_t index_base, const Ray &ray,
-                                                   float *out_t, int32_t *out_prim) {
+                                                   float filter_origin2, float *out_t, int32_t *out_prim) {
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
     const uint32_t ex_face = (ray.excl >> 29) & 3u;
@@ -132,6 +145,8 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
     const unsigned long long keep_front = __builtin_amdgcn_ballot_w64(ray.mode != FACE_BACK);
     const unsigned long long ex_if_back = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_FRONT);  /* Back or Both */
     const unsigned long long ex_if_front = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_BACK);  /* Front or Both */
+    /* lanes whose origin is inside the scene's neighbourhood may use the bounding-sphere rejection (rt_device_scene.h) */
+    const unsigned long long filter_ok = __builtin_amdgcn_ballot_w64(dot(ray.o, ray.o) <= filter_origin2);
     const uint32_t exid = (ex_some && ex_prim >= index_base && ex_prim - index_base < n) ? ex_prim - index_base : 0xffffffffu;
     float best_t = rtdm::quiet_nan();
     int32_t best_prim = -1;
@@ -141,12 +156,21 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
     const unsigned long long ptr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ptr_v >> 32)) << 32) |
                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ptr_v);
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+#ifdef RT_DIAG_STAGES
+    uint32_t stage_counts[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#endif
     asm volatile(RT_CAST_ASM_TEXT
                  : "+v"(best_t), "+v"(best_prim), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6),
-                   "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12)
+                   "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12) RT_STAGE_OPERANDS
                  : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(keep_back),
-                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(n)
+                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(n), "s"(filter_ok)
                  : RT_CAST_ASM_CLOBBERS);
+#ifdef RT_DIAG_STAGES
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { /* first active lane: the counts are wave-uniform */
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_stage_totals[k], (unsigned long long)stage_counts[k]);
+        atomicAdd(&g_stage_totals[7], 1ull); /* casts (per wave) */
+    }
+#endif
     *out_t = best_t;
     *out_prim = best_prim >= 0 ? best_prim + (int32_t)index_base : -1;
 }
@@ -205,7 +229,7 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
 __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
     float best_t;
     int32_t best_prim;
-    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, &best_t, &best_prim);
+    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, sc.filter_origin2, &best_t, &best_prim);
     return cast_finish(sc, ray, best_t, best_prim);
 }
 

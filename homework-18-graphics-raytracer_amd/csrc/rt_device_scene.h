@@ -12,6 +12,14 @@
  *   area = ((v1-v0) x (v2-v0)) . n           main.rs:235
  *   r2  = radius * radius                    main.rs:272 (powi(2))
  *
+ * Bounding sphere (bc, bq): centre and 1.05 x squared radius of the triangle's minimal enclosing circle.  The
+ * intersection loop uses it for a CONSERVATIVE rejection only — a plane hit point farther than that from the
+ * centre is outside the triangle by a margin far above the rounding error of the reference's signed areas, so
+ * the areas need not be evaluated to know that one of them is negative (rt_cast_asm.h).  It never decides an
+ * accept, so results stay bit-identical.  rt_scene_create switches it off (bq = +inf) for triangles where that
+ * argument would be thin: slivers (an angle under ~1.15 degrees), non-finite or huge coordinates, triangles tiny
+ * against the scene's extent; rays whose origin is far outside the scene do not use it either (filter_origin2).
+ *
  * DevTri is 128 bytes; the intersection loop indexes it with a wave-uniform index
  * and fetches its first 112 bytes with scalar loads (s_load_dwordx16 + x8 + x4)
  * into SGPRs (rt_cast_asm.h), or the kernel stages it in LDS (variant bit 0) —
@@ -28,10 +36,10 @@ struct alignas(32) DevTri {
     float n[3];  float d;          /* plane */
     float v0[3]; uint32_t obj;
     float v1[3]; float area;       /* area of the whole triangle (barycentric denominator) */
-    float v2[3]; float pad0;
-    float e0[3]; float pad1;       /* v2 - v1 */
-    float e1[3]; float pad2;       /* v0 - v2 */
-    float e2[3]; float pad3;       /* v1 - v0 */
+    float v2[3]; float bq;         /* bounding sphere: 1.05 R^2, +inf = filter off (see below) */
+    float e0[3]; float bcx;        /* v2 - v1            | bounding-sphere centre x */
+    float e1[3]; float bcy;        /* v0 - v2            |                        y */
+    float e2[3]; float bcz;        /* v1 - v0            |                        z */
     float pad4[4];
 };
 static_assert(sizeof(DevTri) == 128, "DevTri must be 128 bytes");

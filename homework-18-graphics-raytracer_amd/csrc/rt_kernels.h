@@ -33,7 +33,9 @@
 #define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
 #define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
 #define RT_VARIANT_COOP 8         /* bit 3: cooperative workgroups — four waves split every tile's triangle loop */
-#define RT_VARIANT_MAX 15
+#define RT_VARIANT_WAVEFRONT 16   /* bit 4: level-synchronous wavefront (rt_wavefront.hip); the bits below pick its overflow fallback */
+#define RT_VARIANT_PWF 32         /* bit 5: one persistent kernel of workgroup-local wavefronts (rt_pwf.hip) */
+#define RT_VARIANT_MAX 63
 #define RT_VARIANT_DEFAULT (RT_VARIANT_SGPR | RT_VARIANT_STATIC)
 #define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 
@@ -47,6 +49,7 @@ struct KernelScene {
     const rt_material *materials;
     const rt_light *lights;
     uint32_t n_triangles, n_spheres, n_materials, n_lights;
+    float filter_origin2; /* rays with |origin|^2 above this skip the bounding-sphere rejection (rt_device_scene.h) */
 };
 
 /* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),
@@ -77,6 +80,7 @@ struct KernelQueues {
     uint32_t *class_count;         /* RT_PROBE_CLASSES counters (zeroed per launch): chunks filed under each cost class */
     uint32_t *tile_order;          /* RT_PROBE_CLASSES lists of n_chunks chunk ids (RT_VARIANT_SORTED) */
     unsigned long long *timeline;  /* diagnostic builds (RT_DIAG_TIMELINE): 4 u64 per wave, else unused */
+    const uint32_t *run_if;        /* when set: the kernel is a no-op unless *run_if != 0 (the wavefront path's overflow fallback) */
 };
 
 uint32_t cont_record_dwords(int32_t max_depth);
@@ -84,6 +88,50 @@ void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hoo
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                           const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
+
+/* wavefront path (rt_wavefront.hip) */
+#define WF_C_LEVEL 0u        /* [RT_MAX_DEPTH + 2] nodes per level                      */
+#define WF_C_NODE_WORK 40u   /* [..] chunk counters of wf_node                          */
+#define WF_C_REFR_COUNT 80u  /* [..] refraction tasks per level                         */
+#define WF_C_REFR_WORK 120u  /* [..] chunk counters of wf_refr                          */
+#define WF_C_SHADE_COUNT 160u
+#define WF_C_SHADE_WORK 161u
+#define WF_C_OVERFLOW 162u   /* raised when a list outgrew its capacity: the frame is re-rendered by the per-pixel kernel */
+#define WF_C_CASTS 164u      /* u64 */
+#define WF_COUNTER_WORDS 192u
+struct WfBuffers {
+    uint32_t *counters; /* WF_COUNTER_WORDS u32, initialised by the launch */
+    uint4 *node_in;     /* capacity x 2: ray + contribution of every node                          */
+    uint4 *nodes;       /* capacity x 2: shade term, rc | fc, decay, reflection child, refraction child */
+    uint4 *shade;       /* capacity x 4: shade tasks                                               */
+    uint4 *refr;        /* capacity x 3: refraction tasks of the level in flight                   */
+    uint32_t capacity;  /* nodes (all levels together) */
+};
+enum { WF_STAGE_TRACE = 0, WF_STAGE_SHADE = 1, WF_STAGE_COMBINE = 2, WF_STAGES = 3 };
+void set_wavefront_events(hipEvent_t (*events)[2]); /* profiling hook: per-stage event pairs, or null */
+hipError_t launch_wavefront(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const WfBuffers &wb,
+                            uint32_t waves, hipStream_t stream);
+
+/* persistent workgroup-local wavefronts (rt_pwf.hip) */
+#define PW_G_TILE 0u       /* next tile of the frame */
+#define PW_G_OVERFLOW 1u   /* the frame could not be finished within the arenas: the per-pixel kernel renders it */
+#define PW_G_TILES_DONE 2u /* tiles whose pixels were written */
+#define PW_G_CASTS 4u      /* u64 */
+#define PW_G_WORDS 8u
+struct PwParams {
+    uint32_t *global;       /* PW_G_WORDS u32, initialised by the launch */
+    unsigned char *arena;   /* one arena of arena_stride bytes per workgroup */
+    size_t arena_stride;
+    uint32_t node_cap;      /* nodes per arena */
+    uint32_t ring_cap;      /* power of two >= node_cap + 1024: items of the shade and refraction rings */
+    uint32_t tile_reserve;  /* nodes an arena must have free per primary ray before it takes more tiles */
+    uint32_t tile_stride;   /* the k-th tile handed out is (k * tile_stride) mod n_tiles; coprime to n_tiles */
+};
+uint32_t pwf_threads();
+int pwf_workgroups_per_cu();
+size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap);
+hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
+                      uint32_t workgroups, hipStream_t stream);
 
 /* distributed pass (rt_distributed.hip) */
 struct DistParams {

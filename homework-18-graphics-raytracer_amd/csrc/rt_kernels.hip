@@ -152,6 +152,7 @@ template <int MAXD, bool USE_LDS, int MODE>
 __device__ __forceinline__ void whitted_body(const KernelScene &sc, const KernelFrame &fr, float *__restrict__ out,
                                              unsigned long long *__restrict__ ray_count, const KernelQueues &qs) {
     uint32_t *__restrict__ work_queue = qs.work_queue;
+    if (MODE == MODE_STATIC && qs.run_if != nullptr && *qs.run_if == 0u) return; /* fallback launch that is not needed */
     extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
     const DevTri *lds_tris = nullptr;
     if (USE_LDS) {
@@ -422,7 +423,7 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
                     r.d = v3(__uint_as_float(rj[3 * 64]), __uint_as_float(rj[4 * 64]), __uint_as_float(rj[5 * 64]));
                     r.mode = rj[6 * 64];
                     r.excl = rj[7 * 64];
-                    cast_asm_triangles(sc.tris + t_base, t_cnt, t_base, r, &bt, &bp);
+                    cast_asm_triangles(sc.tris + t_base, t_cnt, t_base, r, sc.filter_origin2, &bt, &bp);
                 }
                 uint32_t *res = coop_lds + COOP_RES_OFFSET + ((j * COOP_WAVES + wslot) * 2u) * 64u + lane;
                 res[0] = __float_as_uint(bt);
@@ -442,7 +443,7 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
                         if (!(best_prim >= 0 && best_t < t)) { best_t = t; best_prim = pr; }
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(saw_nan) != 0ull) cast_asm_triangles(sc.tris, nt, 0u, req, &best_t, &best_prim);
+                if (__builtin_amdgcn_ballot_w64(saw_nan) != 0ull) cast_asm_triangles(sc.tris, nt, 0u, req, sc.filter_origin2, &best_t, &best_prim);
                 cr = cast_finish(sc, req, best_t, best_prim);
             }
         }
@@ -854,3 +855,7 @@ void math_eval_host(int op, const float *x, const float *y, float *out, size_t n
 }
 
 } /* namespace rt */
+
+#ifdef RT_DIAG_STAGES
+RT_DIAG_STAGE_READER(rt_diag_read_stages_kernels)
+#endif

@@ -239,9 +239,18 @@ int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d
  *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
  *   bit 3     8: cooperative workgroups: 256-thread groups of four tiles whose four waves split every live
  *                tile's triangle loop (finished waves help the others); bits 1-2 are then ignored
+ *   bit 4     16: level-synchronous wavefront: every ray_trace activation is a work item; per level one kernel for
+ *                the activations' own casts and one for the refraction chains, then one kernel for all shadow
+ *                rays and one combine pass per level (csrc/rt_wavefront.hip).  Same results bit for bit.
  * Default 2, or the value of the RT_AMD_VARIANT environment variable at load. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);
+
+/* Wavefront path (variant bit 4): size of its node arrays, in ray_trace activations per tile pixel (default 6,
+ * RT_AMD_WF_NODES_PER_PIXEL; the reference scene needs 3.4 at depth 8; 176 B of device memory each).  A frame
+ * that needs more is detected on the device and rendered by the per-pixel kernel within the same call, so the
+ * budget changes speed and memory only, never results. */
+int rt_set_wavefront_budget(unsigned nodes_per_pixel);
 
 /* Two-phase (variant 6) tuning: a tile wave parks its remaining lanes once at most `threshold` (0..63) are active
  * and it has done at least `min_iterations` casts.  Defaults 16 / 4 (RT_AMD_EVICT_THRESHOLD,

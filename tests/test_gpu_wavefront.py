@@ -1,0 +1,99 @@
+"""GPU parity of the two wavefront paths: variant bit 4 (csrc/rt_wavefront.hip: every ray_trace activation is a work
+item, levels are kernels) and bit 5 (csrc/rt_pwf.hip: one persistent kernel, workgroup-local queues).  Same bar as the per-pixel kernel: radiance identical bit for bit to the CPU oracle and
+equal World::cast counts — also when the node budget overflows and the per-pixel kernel takes the frame over."""
+import numpy as np
+import pytest
+
+import homework_18_graphics_raytracer_amd as rt
+from homework_18_graphics_raytracer_amd import _capi
+import _oracle
+import _scenes
+
+pytestmark = pytest.mark.gpu
+
+WAVEFRONT = 16
+PWF = 32
+PATHS = [WAVEFRONT | 2, PWF | 2]
+
+
+def _check(world, cam, frame, budget=None, scene=None, variant=WAVEFRONT | 2):
+    lib = _capi.amd_lib()
+    scene = scene or rt.Scene(world)
+    _capi.check(lib.rt_set_variant(variant))
+    if budget is not None:
+        _capi.check(lib.rt_set_wavefront_budget(budget))
+    try:
+        got, casts = rt.render_whitted_numpy(scene, cam, frame)
+    finally:
+        _capi.check(lib.rt_set_variant(2))
+        _capi.check(lib.rt_set_wavefront_budget(6))
+    want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
+    g, w = got.view(np.uint32), want.view(np.uint32)
+    same = (g == w) | (np.isnan(got) & np.isnan(want))  # NaN payload/sign may differ between x86 and gfx950
+    assert same.all(), f"{(~same).sum()} channels differ; first {np.argwhere(~same)[:3].tolist()}"
+    assert casts == wcasts
+    return got
+
+
+@pytest.fixture(scope="module")
+def ref():
+    world = rt.reference_world()
+    return world, rt.reference_camera(), rt.Scene(world)
+
+
+@pytest.mark.parametrize("variant", PATHS)
+@pytest.mark.parametrize("w,h,depth", [(256, 256, 1), (320, 240, 5), (200, 150, 8), (97, 61, 0), (64, 64, 3), (1003, 597, 3)])
+def test_wavefront_bit_exact_on_the_reference_scene(ref, w, h, depth, variant):
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(w, h, depth), scene=scene, variant=variant)
+
+
+@pytest.mark.parametrize("variant", PATHS)
+def test_wavefront_reference_size(ref, variant):
+    """The reference's own configuration: 1280x960, depth 5 (main.rs:1084-1085,1098)."""
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(1280, 960, 5), scene=scene, variant=variant)
+
+
+@pytest.mark.parametrize("variant", PATHS)
+@pytest.mark.parametrize("budget", [1, 2, 3])
+def test_budget_overflow_falls_back_to_the_per_pixel_kernel(ref, budget, variant):
+    """1 node per pixel cannot even hold the first reflections: the overflow flag must hand the whole frame (and
+    its cast count) to the per-pixel kernel; 3 per pixel overflows somewhere in the deeper levels."""
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(200, 150, 8), budget=budget, scene=scene, variant=variant)
+
+
+@pytest.mark.parametrize("variant", PATHS)
+def test_generous_budget(ref, variant):
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(160, 120, 8), budget=64, scene=scene, variant=variant)
+
+
+@pytest.mark.parametrize("seed,nt,ns", [(1, 0, 3), (2, 1, 0), (3, 2, 1), (4, 7, 2), (5, 33, 4), (6, 64, 0), (7, 65, 5), (8, 131, 3), (9, 200, 9)])
+@pytest.mark.parametrize("variant", PATHS)
+def test_wavefront_random_scenes(seed, nt, ns, variant):
+    world = _scenes.random_world(seed, nt, ns)
+    _check(world, _scenes.camera(seed), rt.Frame.full(96, 64, 5), budget=16, variant=variant)
+
+
+@pytest.mark.parametrize("depth", [9, 12, 20, 32])
+@pytest.mark.parametrize("variant", PATHS)
+def test_wavefront_deep_recursion(depth, variant):
+    world = rt.reference_world()
+    _check(world, rt.reference_camera(), rt.Frame.full(80, 60, depth), budget=32, variant=variant)
+
+
+@pytest.mark.parametrize("variant", PATHS)
+def test_wavefront_row_tiles_equal_the_full_frame(ref, variant):
+    """Interleaved row tiles (the multi-GPU sharding) through the wavefront paths."""
+    world, cam, scene = ref
+    full = _check(world, cam, rt.Frame.full(150, 101, 5), scene=scene, variant=variant)
+    lib = _capi.amd_lib()
+    _capi.check(lib.rt_set_variant(variant))
+    try:
+        for rank in range(3):
+            band, _ = rt.render_whitted_numpy(scene, cam, rt.Frame.rows_of_rank(150, 101, 5, rank, 3))
+            assert (band.view(np.uint32) == full[rank::3].view(np.uint32)).all()
+    finally:
+        _capi.check(lib.rt_set_variant(2))

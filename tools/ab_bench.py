@@ -8,6 +8,7 @@ Each tag is homework-18-graphics-raytracer_amd/variants/librt_amd_<tag>.so (make
 """
 import argparse
 import ctypes as C
+import os
 import statistics
 import sys
 import time
@@ -37,9 +38,13 @@ desc = world.desc()
 frame = rt.Frame.full(args.width, args.height, args.depth)
 libs = {}
 for tag in args.tags.split(","):
-    parts = tag.split(":")  # "name", "name:variant" or "name:variant:evict_threshold:evict_min_iter"
+    parts = tag.split(":")  # "name", "name:variant", "name:variant:evict_threshold:evict_min_iter" or "name:variant:ENV=value[;ENV=value]"
     name, var = parts[0], (parts[1] if len(parts) > 1 else "")
     evict = (int(parts[2]), int(parts[3])) if len(parts) > 3 else None
+    env = dict(kv.split("=", 1) for kv in parts[2].split(";")) if len(parts) == 3 else {}
+    for k in ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC"):
+        os.environ.pop(k, None)
+    os.environ.update(env)  # read by rt_scene_create
     path = _capi.PKG_DIR / ("librt_amd.so" if name == "main" else f"variants/librt_amd_{name}.so")
     lib = C.CDLL(str(path))
     lib.rt_last_error.restype = C.c_char_p

@@ -25,11 +25,17 @@ only consumed by SALU (interlocked) and branches use SCC, never VCCZ/EXECZ.
 OUT = {"best_t": 0, "best_prim": 1}
 TEMPS = {f"r{k}": 2 + k for k in range(13)}
 IN = {"ox": 15, "oy": 16, "oz": 17, "dx": 18, "dy": 19, "dz": 20, "exid": 21, "keep_back": 22, "keep_front": 23,
-      "ex_if_back": 24, "ex_if_front": 25, "ptr": 26, "n": 27}
+      "ex_if_back": 24, "ex_if_front": 25, "ptr": 26, "n": 27, "filter_ok": 28}
 
 import sys
+COUNT = "--count-stages" in sys.argv  # diagnostic build (RT_DIAG_STAGES): eight extra "+v" operands count how far each triangle test got
+if COUNT:
+    TEMPS.update({f"c{k}": 15 + k for k in range(8)})
+    IN = {k: v + 8 for k, v in IN.items()}
 EARLY_AREA_EXITS = "--no-early-area-exits" not in sys.argv
 OUT_OF_LINE_EXCLUSION = "--inline-exclusion" not in sys.argv
+SPHERE_FILTER = "--no-sphere-filter" not in sys.argv  # conservative per-triangle bounding-sphere rejection of the plane hit point
+NEAREST_EARLY = "--nearest-late" not in sys.argv      # test !(best_t < t) right after t > 0 instead of after the areas
 ILP = "--ilp" in sys.argv  # interleave the three signed-area chains (and p) for a lone wave; one exit after all three
 XT = [f"v{k}" for k in range(148, 168)]  # extra temporaries of the ILP form: fixed VGPRs, named in the clobber list
 SLOW = {}
@@ -50,8 +56,8 @@ BUF = {
 
 def regs(buf):
     b = BUF[buf]["base"]
-    names = ["nx", "ny", "nz", "d", "v0x", "v0y", "v0z", "obj", "v1x", "v1y", "v1z", "area", "v2x", "v2y", "v2z", "pad0",
-             "e0x", "e0y", "e0z", "pad1", "e1x", "e1y", "e1z", "pad2", "e2x", "e2y", "e2z", "pad3"]
+    names = ["nx", "ny", "nz", "d", "v0x", "v0y", "v0z", "obj", "v1x", "v1y", "v1z", "area", "v2x", "v2y", "v2z", "bq",
+             "e0x", "e0y", "e0z", "bcx", "e1x", "e1y", "e1z", "bcy", "e2x", "e2y", "e2z", "bcz"]
     return {n: f"s{b + k}" for k, n in enumerate(names)}
 
 
@@ -105,6 +111,8 @@ def test(buf, label_next):
     nd, num = r[11], r[12]  # num becomes t
     t = num
     L = []
+    cnt = (lambda k: [f"v_add_u32 {op('c%d' % k)}, 1, {op('c%d' % k)}"]) if COUNT else (lambda k: [])
+    L += cnt(0)
     # nd = n . d ; bf = nd > 0
     L += dot_sv(nd, r[9], n, d)
     L += [f"v_cmp_lt_f32 vcc, 0, {nd}"]
@@ -122,6 +130,7 @@ def test(buf, label_next):
         L += excl
     L += [f"s_and_b64 {S_ALIVE}, {S_ALIVE}, exec", f"s_cbranch_scc0 {label_next}"]
     # num = d - n . o                              (main.rs:203-204)
+    L += cnt(1)
     L += dot_sv(r[9], r[10], n, o)
     L += [f"v_sub_f32 {num}, {T['d']}, {r[9]}"]
     # t = num / nd, correctly rounded (the sequence hipcc emits for an IEEE f32 divide)
@@ -139,8 +148,15 @@ def test(buf, label_next):
           f"v_div_fmas_f32 {q0}, {q0}, {rc}, {q}",
           f"v_div_fixup_f32 {t}, {q0}, {nd}, {num}"]
     # alive &= !(t <= 0)   (NaN passes, main.rs:205)
-    L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    if NEAREST_EARLY:
+        # ... and alive &= !(best_t < t): a lane that already holds a nearer hit cannot accept this triangle whatever its
+        # areas are (main.rs:229-233 is one more `continue`; the order of the rejections is immaterial), best_t = NaN while None
+        L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc",
+              f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    else:
+        L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # p = o + d * t
+    L += cnt(2)
     p = (r[0], r[1], r[2])
     if ILP:
         L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}" for k in range(3)] + [f"v_add_f32 {p[k]}, {o[k]}, {p[k]}" for k in range(3)]
@@ -148,6 +164,20 @@ def test(buf, label_next):
         for k in range(3):
             L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
     w = (r[3], r[4], r[5])
+    if SPHERE_FILTER:
+        # Conservative rejection (rt_device_scene.h "bounding sphere"): the plane hit point p of a lane lies outside the
+        # triangle for sure when q = |p - c|^2 exceeds bq = 1.05 R^2 (c, R: the triangle's enclosing circle) — at least one
+        # signed area is then negative by a margin far above its rounding error.  q must also be finite and moderate
+        # (< 1e30): a non-finite p makes the areas NaN, which the reference ACCEPTS.  NaN q fails both compares (kept).
+        # bq = +inf switches the filter off for a triangle (degenerate, sliver or huge coordinates) — skipped outright.
+        L += [f"s_cmp_eq_u32 {T['bq']}, 0x7f800000", f"s_cbranch_scc1 .Lcast_nofilter{buf}_%="]
+        L += [f"v_subrev_f32 {w[0]}, {T['bcx']}, {p[0]}", f"v_subrev_f32 {w[1]}, {T['bcy']}, {p[1]}", f"v_subrev_f32 {w[2]}, {T['bcz']}, {p[2]}",
+              f"v_mul_f32 {w[0]}, {w[0]}, {w[0]}", f"v_mul_f32 {w[1]}, {w[1]}, {w[1]}", f"v_add_f32 {w[0]}, {w[0]}, {w[1]}",
+              f"v_mul_f32 {w[2]}, {w[2]}, {w[2]}", f"v_add_f32 {w[0]}, {w[0]}, {w[2]}",
+              f"v_cmp_lt_f32_e64 {S_T1}, {T['bq']}, {w[0]}", f"v_cmp_gt_f32 vcc, 0x7149f2ca, {w[0]}",
+              f"s_and_b64 {S_T1}, {S_T1}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {op('filter_ok')}",
+              f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}", f"s_cbranch_scc0 {label_next}",
+              f".Lcast_nofilter{buf}_%=:"]
     e0 = (T["e0x"], T["e0y"], T["e0z"]); e1 = (T["e1x"], T["e1y"], T["e1z"]); e2 = (T["e2x"], T["e2y"], T["e2z"])
     v0 = (T["v0x"], T["v0y"], T["v0z"]); v1 = (T["v1x"], T["v1y"], T["v1z"]); v2 = (T["v2x"], T["v2y"], T["v2z"])
     if ILP:
@@ -166,20 +196,27 @@ def test(buf, label_next):
         # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
         # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
         early = EARLY_AREA_EXITS
+        L += cnt(3)
         L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
         if early:
             L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+        L += cnt(4)
         L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
         if early:
             L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+        L += cnt(5)
         L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
         if early:
             L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
         else:
             L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
-    # nearest: !(best_t < t), best_t = NaN while None (main.rs:229-233)
-    L += [f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    if NEAREST_EARLY:
+        L += [f"s_cbranch_scc0 {label_next}"]
+    else:
+        # nearest: !(best_t < t), best_t = NaN while None (main.rs:229-233)
+        L += [f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # accept for the lanes in alive
+    L += cnt(6)
     L += [f"s_mov_b64 {S_EXSAVE}, exec", f"s_mov_b64 exec, {S_ALIVE}",
           f"v_mov_b32 {op('best_t')}, {t}", f"v_mov_b32 {op('best_prim')}, {S_I}",
           f"s_mov_b64 exec, {S_EXSAVE}"]
