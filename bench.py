@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame: every rank renders its interleaved row band of the frame with the HIP kernel
-(homework-18-graphics-raytracer_amd/csrc/rt_kernels.hip, through the C ABI) and, for N > 1, the bands
+(homework-18-graphics-raytracer_amd/csrc/rt_pwf.hip by default, through the C ABI) and, for N > 1, the bands
 are gathered to rank 0 over RCCL.  Rays = World::cast evaluations (primary + shadow + reflection +
 refraction casts), counted by the kernel itself.  Rank 0 prints ONE JSON line.
 
@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--variant", type=int, default=None, help="kernel variant: bit 0 = LDS broadcast (else SGPR); bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase")
+    p.add_argument("--variant", type=int, default=None, help="kernel variant (include/rt_amd.h): 18 = persistent workgroup-local wavefronts (default); per-pixel kernel: bit 0 LDS broadcast (else SGPR), bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase; 8 cooperative")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
     return p.parse_args()
@@ -172,7 +172,7 @@ def main() -> int:
     ksum, kn = C.c_double(0.0), C.c_uint(0)
     _capi.check(_capi.amd_lib().rt_profile_read(C.byref(ksum), C.byref(kn)))
     _capi.check(_capi.amd_lib().rt_profile_enable(0))
-    kernel_ms = ksum.value / max(1, kn.value)  # rt::whitted_kernel (render) alone
+    kernel_ms = ksum.value / max(1, kn.value)  # the render kernel alone (rt::pwf_kernel, or rt::whitted_kernel)
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
     total_casts = count.clone()
     if distributed:
@@ -195,7 +195,7 @@ def main() -> int:
         if tpath.exists():
             try:
                 rec = json.loads(tpath.read_text())
-                if rec.get("width") == W and rec.get("height") == H and rec.get("depth") == D and world_size == 1:
+                if rec.get("width") == W and rec.get("height") == H and rec.get("depth") == D and world_size == 1 and rec.get("variant", 2) == variant:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -218,7 +218,8 @@ def main() -> int:
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
                 "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0" if distributed else ""),
-                "kernel_variant": ("lds" if variant & 1 else "sgpr") + "+" + {0: "cost-sorted-tiles", 2: "static-tiles", 4: "persistent-lanes", 6: "two-phase"}[variant & 6],
+                "kernel_variant": "persistent-wavefront" if variant & 16 else
+                                  ("lds" if variant & 1 else "sgpr") + "+" + ("cooperative" if variant & 8 else {0: "cost-sorted-tiles", 2: "static-tiles", 4: "persistent-lanes", 6: "two-phase"}[variant & 6]),
             },
             "casts_per_frame": casts_per_frame,
             "casts_per_pixel": round(casts_per_frame / (W * H), 3),
@@ -229,7 +230,8 @@ def main() -> int:
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 5),
                 "traffic": traffic,
-                "kernel": "rt::whitted_kernel<8, false, 0> (the render launch; the probe launch of the same call is in call_ms_avg)",
+                "kernel": "rt::pwf_kernel (the persistent render kernel; its two one-thread bookkeeping launches are in call_ms_avg)" if variant & 16
+                          else "rt::whitted_kernel<8, false, 0> (the render launch; the probe launch of the same call is in call_ms_avg)",
                 "kernel_ms_avg": round(kernel_ms_max, 4),
                 "call_ms_avg": round(call_ms, 4),
                 "flop_per_cast": flop_per_cast,

@@ -120,6 +120,8 @@ class Frame(C.Structure):
 
 
 # every symbol include/rt_amd.h declares (checked by tests/test_capi_symbols.py)
+DEFAULT_VARIANT = 18  # RT_VARIANT_PWF | RT_VARIANT_STATIC (csrc/rt_kernels.h)
+
 AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",

@@ -42,8 +42,6 @@ struct Workspace {
     size_t tiles_n = 0;
     void *d_pwf = nullptr; /* persistent-wavefront path: global words + one arena per workgroup */
     size_t pwf_bytes = 0;
-    void *d_wf = nullptr; /* wavefront path: counters + node inputs + node records + shade tasks + refraction tasks */
-    size_t wf_capacity = 0;
 };
 
 struct rt_scene {
@@ -52,7 +50,6 @@ struct rt_scene {
     rt::KernelScene ks;
     uint32_t resident_waves; /* CUs * 4 SIMDs * RT_MIN_WAVES: the persistent grid */
     uint32_t pwf_workgroups;  /* CUs * resident workgroups of the persistent-wavefront kernel */
-    uint32_t wavefront_waves; /* CUs * 4 SIMDs * 8: the wavefront kernels' persistent grid (the hardware limit of resident waves) */
     std::mutex ws_mutex;
     std::map<hipStream_t, Workspace> workspaces;
 };
@@ -342,7 +339,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
     if (e != hipSuccess || cus <= 0) cus = 256;
     sc->resident_waves = (uint32_t)cus * 4u * (uint32_t)RT_MIN_WAVES;
-    sc->wavefront_waves = (uint32_t)cus * 4u * 8u;
     sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu();
     *out_scene = sc;
     return RT_OK;
@@ -355,7 +351,6 @@ int rt_scene_destroy(rt_scene *scene) {
         if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
         if (kv.second.d_cont) (void)hipFree(kv.second.d_cont);
         if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
-        if (kv.second.d_wf) (void)hipFree(kv.second.d_wf);
         if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
     }
     if (scene->d_blob) e = hipFree(scene->d_blob);
@@ -403,19 +398,14 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     if (rc != RT_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     int variant = current_variant();
-    /* the wavefront path packs the ray's face mode next to a 27-bit primitive id */
-    /* ... and the persistent-wavefront path also the depth left, next to a 21-bit primitive id */
+    /* the persistent-wavefront path packs the ray's face mode and the depth left next to a 21-bit primitive id */
     if ((variant & RT_VARIANT_PWF) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 21)) variant &= ~RT_VARIANT_PWF;
     if ((variant & RT_VARIANT_PWF) && (scene->ks.n_lights >= (1u << 15) || scene->ks.n_materials >= (1u << 16))) variant &= ~RT_VARIANT_PWF;
-    if (variant & RT_VARIANT_PWF) variant &= ~RT_VARIANT_WAVEFRONT;
-    if ((variant & RT_VARIANT_WAVEFRONT) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 27)) variant &= ~RT_VARIANT_WAVEFRONT;
     if (g_wf_nodes_per_pixel < 0) {
         const char *v = getenv("RT_AMD_WF_NODES_PER_PIXEL");
         g_wf_nodes_per_pixel = (v && *v) ? atoi(v) : 6; /* the reference scene needs 3.4 at depth 8 */
         if (g_wf_nodes_per_pixel < 1 || g_wf_nodes_per_pixel > 4096) g_wf_nodes_per_pixel = 6;
     }
-    rt::WfBuffers wb;
-    memset(&wb, 0, sizeof wb);
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);
     uint32_t pw_groups = 0;
@@ -495,30 +485,6 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 256;
             pw_groups = (uint32_t)groups;
         }
-        if (variant & RT_VARIANT_WAVEFRONT) {
-            const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
-            uint64_t capacity = pixels * (uint64_t)g_wf_nodes_per_pixel;
-            if (capacity > 0x7fffffffull) capacity = 0x7fffffffull;
-            if (capacity < pixels) {
-                variant &= ~RT_VARIANT_WAVEFRONT; /* tile too large for 32-bit node ids: per-pixel path */
-            } else {
-                const size_t per_node = (2 + 2 + 4 + 3) * sizeof(uint4);
-                if (capacity > ws.wf_capacity) {
-                    if (ws.d_wf) (void)hipFree(ws.d_wf);
-                    ws.d_wf = nullptr;
-                    ws.wf_capacity = 0;
-                    RT_HIP(hipMalloc(&ws.d_wf, 1024 + (size_t)capacity * per_node));
-                    ws.wf_capacity = (size_t)capacity;
-                }
-                unsigned char *p = static_cast<unsigned char *>(ws.d_wf);
-                wb.counters = reinterpret_cast<uint32_t *>(p);
-                wb.node_in = reinterpret_cast<uint4 *>(p + 1024);
-                wb.nodes = wb.node_in + (size_t)ws.wf_capacity * 2;
-                wb.shade = wb.nodes + (size_t)ws.wf_capacity * 2;
-                wb.refr = wb.shade + (size_t)ws.wf_capacity * 4;
-                wb.capacity = (uint32_t)capacity; /* the budget asked for, even when the allocation is larger */
-            }
-        }
         qs.work_queue = ws.d_counters;
         qs.cont_count = ws.d_counters + 1;
         qs.class_count = ws.d_counters + 2;
@@ -542,12 +508,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         /* a frame that did not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
         qs.run_if = pw.global + PW_G_OVERFLOW;
         variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;
-    }
-    if (e == hipSuccess && (variant & RT_VARIANT_WAVEFRONT)) {
-        e = rt::launch_wavefront(scene->ks, kf, d_rgb, d_ray_count, wb, scene->wavefront_waves, stream);
-        /* a frame that outgrew the node budget is rendered by the per-pixel kernel instead (a no-op otherwise) */
-        qs.run_if = wb.counters + WF_C_OVERFLOW;
-        variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;
+        rt::set_main_kernel_events(nullptr, nullptr); /* the pair brackets the persistent kernel, not the fallback */
     }
     if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);

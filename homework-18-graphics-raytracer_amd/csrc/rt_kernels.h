@@ -29,14 +29,14 @@
 #define RT_VARIANT_LDS 1          /* bit 0: triangle records staged in LDS once per workgroup */
 #define RT_VARIANT_SCHEME_MASK 6  /* bits 1-2: how pixels reach lanes */
 #define RT_VARIANT_SORTED 0       /*   one 8x8 tile per wave, tiles dispatched most-expensive-first (cost probe + class lists) */
-#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (default: as fast as SORTED once the probe is paid for) */
+#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (as fast as SORTED once the probe is paid for) */
 #define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
 #define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
 #define RT_VARIANT_COOP 8         /* bit 3: cooperative workgroups — four waves split every tile's triangle loop */
-#define RT_VARIANT_WAVEFRONT 16   /* bit 4: level-synchronous wavefront (rt_wavefront.hip); the bits below pick its overflow fallback */
-#define RT_VARIANT_PWF 32         /* bit 5: one persistent kernel of workgroup-local wavefronts (rt_pwf.hip) */
-#define RT_VARIANT_MAX 63
-#define RT_VARIANT_DEFAULT (RT_VARIANT_SGPR | RT_VARIANT_STATIC)
+#define RT_VARIANT_PWF 16         /* bit 4: one persistent kernel of workgroup-local wavefronts (rt_pwf.hip, the default); a frame that
+                                   * does not fit its arenas is rendered by the per-pixel kernel on static tiles */
+#define RT_VARIANT_MAX 31
+#define RT_VARIANT_DEFAULT (RT_VARIANT_PWF | RT_VARIANT_SGPR | RT_VARIANT_STATIC)
 #define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 
 namespace rt {
@@ -80,37 +80,15 @@ struct KernelQueues {
     uint32_t *class_count;         /* RT_PROBE_CLASSES counters (zeroed per launch): chunks filed under each cost class */
     uint32_t *tile_order;          /* RT_PROBE_CLASSES lists of n_chunks chunk ids (RT_VARIANT_SORTED) */
     unsigned long long *timeline;  /* diagnostic builds (RT_DIAG_TIMELINE): 4 u64 per wave, else unused */
-    const uint32_t *run_if;        /* when set: the kernel is a no-op unless *run_if != 0 (the wavefront path's overflow fallback) */
+    const uint32_t *run_if;        /* when set: the kernel is a no-op unless *run_if != 0 (the persistent-wavefront path's overflow fallback) */
 };
 
 uint32_t cont_record_dwords(int32_t max_depth);
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hook, see rt_profile_* */
+void record_main_kernel_event(int which, hipStream_t stream);    /* 0: start, 1: stop; no-op when profiling is off */
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                           const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
-
-/* wavefront path (rt_wavefront.hip) */
-#define WF_C_LEVEL 0u        /* [RT_MAX_DEPTH + 2] nodes per level                      */
-#define WF_C_NODE_WORK 40u   /* [..] chunk counters of wf_node                          */
-#define WF_C_REFR_COUNT 80u  /* [..] refraction tasks per level                         */
-#define WF_C_REFR_WORK 120u  /* [..] chunk counters of wf_refr                          */
-#define WF_C_SHADE_COUNT 160u
-#define WF_C_SHADE_WORK 161u
-#define WF_C_OVERFLOW 162u   /* raised when a list outgrew its capacity: the frame is re-rendered by the per-pixel kernel */
-#define WF_C_CASTS 164u      /* u64 */
-#define WF_COUNTER_WORDS 192u
-struct WfBuffers {
-    uint32_t *counters; /* WF_COUNTER_WORDS u32, initialised by the launch */
-    uint4 *node_in;     /* capacity x 2: ray + contribution of every node                          */
-    uint4 *nodes;       /* capacity x 2: shade term, rc | fc, decay, reflection child, refraction child */
-    uint4 *shade;       /* capacity x 4: shade tasks                                               */
-    uint4 *refr;        /* capacity x 3: refraction tasks of the level in flight                   */
-    uint32_t capacity;  /* nodes (all levels together) */
-};
-enum { WF_STAGE_TRACE = 0, WF_STAGE_SHADE = 1, WF_STAGE_COMBINE = 2, WF_STAGES = 3 };
-void set_wavefront_events(hipEvent_t (*events)[2]); /* profiling hook: per-stage event pairs, or null */
-hipError_t launch_wavefront(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const WfBuffers &wb,
-                            uint32_t waves, hipStream_t stream);
 
 /* persistent workgroup-local wavefronts (rt_pwf.hip) */
 #define PW_G_TILE 0u       /* next tile of the frame */

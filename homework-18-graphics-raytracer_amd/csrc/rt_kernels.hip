@@ -748,6 +748,10 @@ static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, floa
 /* optional HIP events recorded on the launch stream right around the dominant (render) kernel of a call */
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+void record_main_kernel_event(int which, hipStream_t stream) {
+    hipEvent_t ev = which == 0 ? g_ev_start : g_ev_stop;
+    if (ev) (void)hipEventRecord(ev, stream);
+}
 
 template <int MAXD, int MODE>
 static hipError_t launch_main(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,

@@ -1,5 +1,5 @@
 /*
- * rt_pwf.hip — the Whitted render path as ONE persistent kernel of workgroup-local wavefronts (RT_VARIANT_PWF).
+ * rt_pwf.hip — the Whitted render path as ONE persistent kernel of workgroup-local wavefronts (RT_VARIANT_PWF, the default).
  *
  * The per-pixel kernel (rt_kernels.hip) keeps a lane on one pixel for its whole ray tree: ~50 dependent casts for the
  * deepest pixels bound the frame, a wave's lanes sit in different phases (so the code between two casts runs once per
@@ -41,15 +41,17 @@
 
 namespace rt {
 
+#ifndef PW_WAVES
 #define PW_WAVES 8u
+#endif
 #define PW_THREADS (PW_WAVES * 64u)
 #define PW_TILE_BATCH 8u      /* tiles fetched per global atomic and turned into root nodes by one wave */
 #ifndef PW_ROUNDS
-#define PW_ROUNDS 3u /* chunks a wave may take per iteration when that many are queued: fewer barriers per cast while there is
+#define PW_ROUNDS 4u /* chunks a wave may take per iteration when that many are queued: fewer barriers per cast while there is
                       * plenty of work; one chunk per wave (the shortest step for the dependent chains) when there is not */
 #endif
 #ifndef PW_PENDING_CHUNKS
-#define PW_PENDING_CHUNKS (2u * PW_WAVES) /* a workgroup takes new tiles only while fewer chunks than this are queued: tiles must last
+#define PW_PENDING_CHUNKS 12u /* a workgroup takes new tiles only while fewer chunks than this are queued: tiles must last
                                            * to the end of the frame, or the workgroups that met the expensive ones finish long after the rest */
 #endif
 #define PW_NO_CHILD 0xffffffffu
@@ -159,7 +161,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
         /* ---- the iteration's schedule: the same arithmetic in every wave ---- */
         const uint32_t availN = n_alloc - n_taken, availF = f_alloc - f_taken, availS = s_alloc - s_taken;
         const uint32_t fullN = availN >> 6, fullF = availF >> 6, fullS = availS >> 6;
+#ifdef PW_EXP_FAST /* experiment: short iterations while dependent chains are queued, long ones for pure shade work */
+        uint32_t slots = (fullN + fullF != 0u) ? PW_WAVES * PW_EXP_FAST : PW_WAVES * PW_ROUNDS;
+#else
         uint32_t slots = PW_WAVES * PW_ROUNDS;
+#endif
         /* fresh tiles while the critical queues are short: one wave turns the fetched batch into root nodes */
         const uint32_t tT = (tile_count != 0u && fullN + fullF + fullS < PW_PENDING_CHUNKS) ? 1u : 0u; slots -= tT;
         const uint32_t tN = fullN < slots ? fullN : slots; slots -= tN;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
             }
         }
         /* the chunks of this iteration, dealt round-robin: tiles first (their rays are due next time), then NODE, REFR, SHADE */
-        const uint32_t cN = tN + pN, cF = tF + pF, cS = tS + pS;
+        const uint32_t cN = tN + pN, cF = tF + pF;
         for (uint32_t v = wave; v < busy; v += PW_WAVES) {
             uint32_t type, start = 0u, count = 0u;
             {
@@ -653,7 +659,9 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
     g_pw_last_groups = workgroups;
 #endif
     hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global);
+    record_main_kernel_event(0, stream);
     hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PW_THREADS), 0, stream, sc, fr, pp, out);
+    record_main_kernel_event(1, stream);
     hipLaunchKernelGGL(pwf_finish_kernel, dim3(1), dim3(1), 0, stream, pp.global, fr.n_chunks, ray_count);
     return hipGetLastError();
 }

@@ -239,17 +239,18 @@ int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d
  *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
  *   bit 3     8: cooperative workgroups: 256-thread groups of four tiles whose four waves split every live
  *                tile's triangle loop (finished waves help the others); bits 1-2 are then ignored
- *   bit 4     16: level-synchronous wavefront: every ray_trace activation is a work item; per level one kernel for
- *                the activations' own casts and one for the refraction chains, then one kernel for all shadow
- *                rays and one combine pass per level (csrc/rt_wavefront.hip).  Same results bit for bit.
- * Default 2, or the value of the RT_AMD_VARIANT environment variable at load. */
+ *   bit 4     16: persistent workgroup-local wavefronts (csrc/rt_pwf.hip): one kernel whose workgroups keep queues of
+ *                single-cast work items (a ray_trace activation's own cast, one cast of get_refract, one shadow cast
+ *                of get_shade) and fold the results bottom-up at the end; a frame that does not fit the arenas is
+ *                rendered by the per-pixel kernel selected by the bits below.  Same results bit for bit.
+ * Default 18 (16 | 2), or the value of the RT_AMD_VARIANT environment variable at load. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);
 
-/* Wavefront path (variant bit 4): size of its node arrays, in ray_trace activations per tile pixel (default 6,
- * RT_AMD_WF_NODES_PER_PIXEL; the reference scene needs 3.4 at depth 8; 176 B of device memory each).  A frame
- * that needs more is detected on the device and rendered by the per-pixel kernel within the same call, so the
- * budget changes speed and memory only, never results. */
+/* Persistent-wavefront path (variant bit 4): size of its arenas, in ray_trace activations per tile pixel (default 6,
+ * RT_AMD_WF_NODES_PER_PIXEL; the reference scene needs 3.4 at depth 8; about 200 B of device memory each, rounded up
+ * to a power of two per workgroup).  A frame that needs more is detected on the device and rendered by the per-pixel
+ * kernel within the same call, so the budget changes speed and memory only, never results. */
 int rt_set_wavefront_budget(unsigned nodes_per_pixel);
 
 /* Two-phase (variant 6) tuning: a tile wave parks its remaining lanes once at most `threshold` (0..63) are active

@@ -20,7 +20,7 @@ def _check(world, cam, frame, variant=2):
     try:
         got, casts = rt.render_whitted_numpy(scene, cam, frame)
     finally:
-        _capi.check(_capi.amd_lib().rt_set_variant(2))
+        _capi.check(_capi.amd_lib().rt_set_variant(_capi.DEFAULT_VARIANT))
     want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
     g, w = got.view(np.uint32), want.view(np.uint32)
     same = (g == w) | (np.isnan(got) & np.isnan(want))  # NaN payload/sign may differ between x86 and gfx950

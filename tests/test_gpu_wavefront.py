@@ -1,6 +1,7 @@
-"""GPU parity of the two wavefront paths: variant bit 4 (csrc/rt_wavefront.hip: every ray_trace activation is a work
-item, levels are kernels) and bit 5 (csrc/rt_pwf.hip: one persistent kernel, workgroup-local queues).  Same bar as the per-pixel kernel: radiance identical bit for bit to the CPU oracle and
-equal World::cast counts — also when the node budget overflows and the per-pixel kernel takes the frame over."""
+"""GPU parity of the persistent-wavefront path (variant bit 4, csrc/rt_pwf.hip: one persistent kernel whose workgroups
+keep queues of single-cast work items), the default render path.  Same bar as the per-pixel kernel: radiance identical
+bit for bit to the CPU oracle and equal World::cast counts — also when a frame does not fit the arenas and the
+per-pixel kernel takes it over."""
 import numpy as np
 import pytest
 
@@ -11,12 +12,11 @@ import _scenes
 
 pytestmark = pytest.mark.gpu
 
-WAVEFRONT = 16
-PWF = 32
-PATHS = [WAVEFRONT | 2, PWF | 2]
+PWF = 16
+PATHS = [PWF | 2]
 
 
-def _check(world, cam, frame, budget=None, scene=None, variant=WAVEFRONT | 2):
+def _check(world, cam, frame, budget=None, scene=None, variant=PWF | 2):
     lib = _capi.amd_lib()
     scene = scene or rt.Scene(world)
     _capi.check(lib.rt_set_variant(variant))
@@ -25,7 +25,7 @@ def _check(world, cam, frame, budget=None, scene=None, variant=WAVEFRONT | 2):
     try:
         got, casts = rt.render_whitted_numpy(scene, cam, frame)
     finally:
-        _capi.check(lib.rt_set_variant(2))
+        _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
         _capi.check(lib.rt_set_wavefront_budget(6))
     want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
     g, w = got.view(np.uint32), want.view(np.uint32)
@@ -96,4 +96,4 @@ def test_wavefront_row_tiles_equal_the_full_frame(ref, variant):
             band, _ = rt.render_whitted_numpy(scene, cam, rt.Frame.rows_of_rank(150, 101, 5, rank, 3))
             assert (band.view(np.uint32) == full[rank::3].view(np.uint32)).all()
     finally:
-        _capi.check(lib.rt_set_variant(2))
+        _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
