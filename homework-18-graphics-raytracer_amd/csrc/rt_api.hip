@@ -454,11 +454,13 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         if (variant & RT_VARIANT_PWF) {
             const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
             const uint64_t tiles = (pixels + 63u) / 64u;
-            uint64_t groups = (tiles + 7u) / 8u; /* a workgroup fetches tiles eight at a time */
+            uint64_t groups = tiles; /* a workgroup fetches one to eight tiles at a time */
             if (groups > scene->pwf_workgroups) groups = scene->pwf_workgroups;
             if (groups < 1) groups = 1;
             const uint64_t want = (pixels * (uint64_t)g_wf_nodes_per_pixel + groups - 1) / groups; /* nodes per arena */
-            uint64_t ring = 2048;
+            /* tiles are handed out dynamically, so a workgroup may end up with several times the average: arenas have a
+             * floor of 8192 ring slots (1.5 MB) however small the frame (budgets below 4 waive it: tests of the fallback) */
+            uint64_t ring = g_wf_nodes_per_pixel >= 4 ? 8192 : 2048;
             while (ring < want + 1024u && ring < (1ull << 30)) ring <<= 1;
             pw.ring_cap = (uint32_t)ring;
             pw.node_cap = (uint32_t)(ring - 1024u);
@@ -482,6 +484,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 ws.pwf_bytes = need;
             }
             pw.global = static_cast<uint32_t *>(ws.d_pwf);
+            pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 128);
+            static_assert(sizeof(rt::KernelFrame) <= 128, "the frame description must fit its slot of the workspace header");
             pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 256;
             pw_groups = (uint32_t)groups;
         }

@@ -115,9 +115,8 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
 /* ---- World::cast with the hand-scheduled triangle loop (rt_cast_asm.h, tools/gen_cast_asm.py) ----------
  * The asm block does main.rs:183-233 for all triangles and returns, per lane, the nearest accepted travel
  * distance and triangle index (best_t = NaN / best_prim = -1 while None: `nearest_t < t` is false for NaN,
- * which is exactly the reference's Option::None case).  The signed areas and the backface flag of the winner
- * are pure functions of (ray, triangle, t) and are re-evaluated once after the loop with the same operations;
- * the sphere loop (main.rs:264-324) stays in C++. */
+ * which is exactly the reference's Option::None case), together with the winner's n.d (whose sign is the backface
+ * flag) and three signed areas as they stood when it was accepted.  The sphere loop (main.rs:264-324) stays in C++. */
 #ifdef RT_DIAG_STAGES /* diagnostic build: python tools/gen_cast_asm.py --count-stages > csrc/rt_cast_asm_diag.h */
 #include "rt_cast_asm_diag.h"
 #define RT_STAGE_OPERANDS , "+v"(stage_counts[0]), "+v"(stage_counts[1]), "+v"(stage_counts[2]), "+v"(stage_counts[3]), "+v"(stage_counts[4]), "+v"(stage_counts[5]), "+v"(stage_counts[6]), "+v"(stage_counts[7])
@@ -136,7 +135,7 @@ static __device__ unsigned long long g_stage_totals[8]; /* per translation unit;
 /* The asm part over the triangle range [index_base, index_base + n): returns the range's nearest accepted hit
  * under the reference's sequential rule, as (best_t, best_prim) with best_prim a GLOBAL triangle index or -1. */
 __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uint32_t n, uint32_t index_base, const Ray &ray,
-                                                   float filter_origin2, float *out_t, int32_t *out_prim) {
+                                                   float filter_origin2, float *out_t, int32_t *out_prim, float *out_nd_areas = nullptr) {
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
     const uint32_t ex_face = (ray.excl >> 29) & 3u;
@@ -150,7 +149,8 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
     const uint32_t exid = (ex_some && ex_prim >= index_base && ex_prim - index_base < n) ? ex_prim - index_base : 0xffffffffu;
     float best_t = rtdm::quiet_nan();
     int32_t best_prim = -1;
-    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12;
+    float best_nd = 0.0f, best_a0 = 0.0f, best_a1 = 0.0f, best_a2 = 0.0f;
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13;
     /* the range is wave-uniform by construction; say so, so that it is passed in SGPRs */
     const unsigned long long ptr_v = (unsigned long long)(uintptr_t)tris_range;
     const unsigned long long ptr = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ptr_v >> 32)) << 32) |
@@ -160,8 +160,9 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
     uint32_t stage_counts[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
     asm volatile(RT_CAST_ASM_TEXT
-                 : "+v"(best_t), "+v"(best_prim), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6),
-                   "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11), "=&v"(r12) RT_STAGE_OPERANDS
+                 : "+v"(best_t), "+v"(best_prim), "+v"(best_nd), "+v"(best_a0), "+v"(best_a1), "+v"(best_a2), "=&v"(r0), "=&v"(r1),
+                   "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11),
+                   "=&v"(r12), "=&v"(r13) RT_STAGE_OPERANDS
                  : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(keep_back),
                    "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(n), "s"(filter_ok)
                  : RT_CAST_ASM_CLOBBERS);
@@ -173,11 +174,18 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
 #endif
     *out_t = best_t;
     *out_prim = best_prim >= 0 ? best_prim + (int32_t)index_base : -1;
+    if (out_nd_areas != nullptr) {
+        out_nd_areas[0] = best_nd;
+        out_nd_areas[1] = best_a0;
+        out_nd_areas[2] = best_a1;
+        out_nd_areas[3] = best_a2;
+    }
 }
 
 /* Everything of World::cast after the triangle loop: the winner's backface flag and signed areas, then the
  * sphere loop (main.rs:264-324), starting from the triangles' nearest hit. */
-__device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim) {
+__device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim,
+                                                  const float *nd_areas = nullptr) {
     const uint32_t nt = sc.n_triangles;
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
@@ -188,7 +196,12 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
     best.bf = 0u;
     best.a0 = best.a1 = best.a2 = 0.0f;
     bool have = best_prim >= 0;
-    if (have) { /* the winner's backface flag and signed areas (main.rs:184, 218-222), same operations as in the loop */
+    if (have && nd_areas != nullptr) { /* kept by the loop at the accept: n.d and the three signed areas of the winner */
+        best.bf = nd_areas[0] > 0.0f ? 1u : 0u;
+        best.a0 = nd_areas[1];
+        best.a1 = nd_areas[2];
+        best.a2 = nd_areas[3];
+    } else if (have) { /* the winner's backface flag and signed areas (main.rs:184, 218-222), same operations as in the loop */
         const DevTri &T = sc.tris[best_prim];
         const V3 n = v3(T.n[0], T.n[1], T.n[2]);
         best.bf = dot(n, ray.d) > 0.0f ? 1u : 0u;
@@ -229,8 +242,9 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
 __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
     float best_t;
     int32_t best_prim;
-    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, sc.filter_origin2, &best_t, &best_prim);
-    return cast_finish(sc, ray, best_t, best_prim);
+    float nd_areas[4];
+    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, sc.filter_origin2, &best_t, &best_prim, nd_areas);
+    return cast_finish(sc, ray, best_t, best_prim, nd_areas);
 }
 
 /* What the state machine keeps of a Hit (main.rs:139-147). */

@@ -98,6 +98,7 @@ hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *o
 #define PW_G_WORDS 8u
 struct PwParams {
     uint32_t *global;       /* PW_G_WORDS u32, initialised by the launch */
+    const KernelFrame *frame; /* the frame description, in device memory (filled by the launch) */
     unsigned char *arena;   /* one arena of arena_stride bytes per workgroup */
     size_t arena_stride;
     uint32_t node_cap;      /* nodes per arena */

@@ -76,6 +76,8 @@ struct PwShared {
     uint32_t tiles_exhausted;          /* the frame-wide counter ran out, or this arena has no room for more tiles */
     uint32_t tile_list_count;          /* tiles this workgroup started */
     uint32_t abort;                    /* arena overflow: stop; the frame falls back to the per-pixel kernel */
+    uint32_t next_chunk;               /* chunks of the running iteration handed out so far */
+    uint32_t tiles_seen;               /* the frame-wide tile counter as of this workgroup's last fetch */
 };
 
 __device__ __forceinline__ uint32_t pfu(float x) { return __float_as_uint(x); }
@@ -116,9 +118,11 @@ __device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t 
     return false;
 }
 
-__global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const KernelScene sc, const KernelFrame fr, const PwParams pp,
-                                                                        float *__restrict__ out) {
+/* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read twice per tile, and as
+ * a by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
+__global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     __shared__ PwShared S;
+    const KernelFrame &fr = *pp.frame;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t total_slots = fr.cols * fr.rows;
@@ -143,10 +147,11 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
         S.tiles_exhausted = 0u;
         S.tile_list_count = 0u;
         S.abort = 0u;
+        S.tiles_seen = 0u;
     }
     uint32_t casts = 0u;
 #ifdef PW_STATS /* diagnostic build: iteration and slot-use totals into the global words */
-    uint32_t st_iter = 0u, st_n = 0u, st_f = 0u, st_t = 0u, st_s = 0u, st_partial = 0u;
+    uint32_t st_iter = 0u, st_n = 0u, st_f = 0u, st_t = 0u, st_s = 0u, st_partial = 0u, st_work = 0u, st_exh_t = 0u, st_exh_iter = 0u, st_exh_pend = 0u;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -161,8 +166,8 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
         /* ---- the iteration's schedule: the same arithmetic in every wave ---- */
         const uint32_t availN = n_alloc - n_taken, availF = f_alloc - f_taken, availS = s_alloc - s_taken;
         const uint32_t fullN = availN >> 6, fullF = availF >> 6, fullS = availS >> 6;
-#ifdef PW_EXP_FAST /* experiment: short iterations while dependent chains are queued, long ones for pure shade work */
-        uint32_t slots = (fullN + fullF != 0u) ? PW_WAVES * PW_EXP_FAST : PW_WAVES * PW_ROUNDS;
+#ifdef PW_EXP_ENDGAME /* experiment: short iterations once no more tiles can be had */
+        uint32_t slots = (exhausted != 0u && tile_count == 0u) ? PW_WAVES * PW_EXP_ENDGAME : PW_WAVES * PW_ROUNDS;
 #else
         uint32_t slots = PW_WAVES * PW_ROUNDS;
 #endif
@@ -182,44 +187,58 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
         const uint32_t busy = tN + pN + tF + pF + tT + tS + pS;
         if (busy == 0u && tile_count == 0u && exhausted != 0u) break; /* nothing queued, nothing left to fetch */
 #ifdef PW_STATS
+        if (st_exh_t == 0u && exhausted != 0u && tile_count == 0u) {
+            st_exh_t = (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_t0); st_exh_iter = st_iter;
+            st_exh_pend = fullN | (fullF << 10) | (fullS << 20);
+        }
         st_iter += 1u; st_n += tN + pN; st_f += tF + pF; st_t += tT; st_s += tS + pS; st_partial += pN + pF + pS;
 #endif
 
         const uint32_t my_tile = lane < PW_TILE_BATCH ? S.tile_buf[lane] : 0u; /* thread 0 may refill the buffer after (B) */
+        if (threadIdx.x == 0u) S.next_chunk = PW_WAVES; /* the first PW_WAVES chunks go to the waves by number, the rest to whoever is free */
         __syncthreads(); /* (B) everyone has read the queue state */
+        /* Fetch tiles one iteration before they can be needed, and only as many as there are waves that would otherwise
+         * have nothing queued next time: a tile's work cannot be predicted (64 primary rays can grow into thousands of
+         * casts), so tiles must last to the end of the frame and be handed out in small portions, or the workgroups that
+         * met the expensive ones finish long after the rest.  The atomic is issued here and its result used after this
+         * iteration's chunks, so its latency is not on the iteration's path. */
+        uint32_t fetch_need = 0u, fetch_first = 0u;
         if (threadIdx.x == 0u) {
             S.n_taken = n_taken + takeN;
             S.f_taken = f_taken + takeF;
             S.s_taken = s_taken + takeS;
             if (tT != 0u) S.tile_count = 0u;
-            /* Fetch tiles one iteration before they can be needed, and only as many as there are waves that would
-             * otherwise have nothing queued next time: a tile's work cannot be predicted (64 primary rays can grow into
-             * thousands of casts), so tiles must last to the end of the frame and be handed out in small portions, or the
-             * workgroups that met the expensive ones finish long after the rest. */
             const uint32_t left_over = (fullN - tN) + (fullF - tF) + (fullS - tS);
-            const uint32_t need = left_over < PW_WAVES ? PW_WAVES - left_over : 0u;
+            uint32_t need = left_over < PW_WAVES ? PW_WAVES - left_over : 0u;
+            /* ... and never more than a fair share of what is left (guided self-scheduling): the last tiles of a frame, or
+             * all tiles of a small one, are spread over the workgroups one at a time */
+            const uint32_t seen = S.tiles_seen;
+            const uint32_t share = (n_tiles - (seen < n_tiles ? seen : n_tiles)) / (2u * gridDim.x);
+            if (need > share) need = share != 0u ? share : (need != 0u ? 1u : 0u);
             if ((tT != 0u || tile_count == 0u) && exhausted == 0u && need != 0u) {
                 /* room for the batch's rays with a margin for their trees: stop taking tiles when the arena is nearly full */
                 const uint32_t room = pp.node_cap - (n_alloc < pp.node_cap ? n_alloc : pp.node_cap);
-                if (room < PW_TILE_BATCH * 64u * pp.tile_reserve || S.tile_list_count + PW_TILE_BATCH > tile_cap) {
+                if (room < need * 64u * pp.tile_reserve || S.tile_list_count + need > tile_cap) {
                     S.tiles_exhausted = 1u;
                 } else {
-                    const uint32_t first = atomicAdd(pp.global + PW_G_TILE, need);
-                    uint32_t got = 0u;
-                    for (uint32_t k = 0; k < need; ++k)
-                        if (first + k < n_tiles) /* consecutive fetches land far apart in the image (tile_stride is coprime to n_tiles) */
-                            S.tile_buf[got++] = (uint32_t)(((unsigned long long)(first + k) * pp.tile_stride) % n_tiles);
-                    S.tile_count = got;
-                    if (first + need >= n_tiles) S.tiles_exhausted = 1u;
+                    fetch_need = need;
+                    fetch_first = atomicAdd(pp.global + PW_G_TILE, need);
                 }
             }
         }
         /* the chunks of this iteration, dealt round-robin: tiles first (their rays are due next time), then NODE, REFR, SHADE */
         const uint32_t cN = tN + pN, cF = tF + pF;
-        for (uint32_t v = wave; v < busy; v += PW_WAVES) {
+#ifdef PW_STATS
+        const unsigned long long st_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        for (uint32_t v = wave; v < busy;) {
             uint32_t type, start = 0u, count = 0u;
             {
                 uint32_t w = v;
+                /* this wave's next chunk: whichever is next when it gets here (waves that drew short chunks take more of them) */
+                uint32_t nx = 0u;
+                if (lane == 0u) nx = atomicAdd(&S.next_chunk, 1u);
+                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
                 if (w < tT) { type = PW_T_TILES; }
                 else if ((w -= tT) < cN) { type = PW_T_NODE; start = n_taken + w * 64u; count = takeN - w * 64u; }
                 else if ((w -= cN) < cF) { type = PW_T_REFR; start = f_taken + w * 64u; count = takeF - w * 64u; }
@@ -527,9 +546,27 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
             }
     
         }
+#ifdef PW_STATS
+        st_work += (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_w0);
+#endif
+        if (wave == 0u) { /* the tiles fetched above: lane k files the k-th one (read after the next barrier) */
+            fetch_need = (uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_need);
+            fetch_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_first);
+            if (fetch_need != 0u) {
+                const uint32_t got = fetch_first >= n_tiles ? 0u : (n_tiles - fetch_first < fetch_need ? n_tiles - fetch_first : fetch_need);
+                /* consecutive fetches land far apart in the image (tile_stride is coprime to n_tiles) */
+                if (lane < got) S.tile_buf[lane] = (uint32_t)(((unsigned long long)(fetch_first + lane) * pp.tile_stride) % n_tiles);
+                if (lane == 0u) {
+                    S.tiles_seen = fetch_first + fetch_need;
+                    S.tile_count = got;
+                    if (fetch_first + fetch_need >= n_tiles) S.tiles_exhausted = 1u;
+                }
+            }
+        }
     }
 
 #ifdef PW_STATS
+    if (lane == 0u) atomicAdd(pp.global + 19, st_work); /* 100 MHz ticks the waves spent on their chunks */
     if (threadIdx.x == 0u) {
         const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
         atomicAdd(pp.global + 8, st_iter); atomicAdd(pp.global + 9, st_n); atomicAdd(pp.global + 10, st_f);
@@ -606,15 +643,16 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
     if (threadIdx.x == 0u) { /* per-workgroup record over the (dead) start of the arena */
         uint32_t *rec = reinterpret_cast<uint32_t *>(arena);
         rec[0] = st_iter; rec[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - st_t0); rec[2] = S.n_alloc; rec[3] = S.tile_list_count;
-        rec[4] = (uint32_t)(st_t0 & 0xffffffffu); rec[5] = st_n; rec[6] = st_f; rec[7] = st_s;
+        rec[4] = (uint32_t)(st_t0 & 0xffffffffu); rec[5] = st_exh_t; rec[6] = st_exh_iter; rec[7] = st_exh_pend;
     }
 #endif
     for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
     if (lane == 0u && casts != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), (unsigned long long)casts);
 }
 
-__global__ void pwf_init_kernel(uint32_t *global) {
+__global__ void pwf_init_kernel(uint32_t *global, KernelFrame *frame, const KernelFrame fr) {
     if (threadIdx.x < 32u) global[threadIdx.x] = 0u; /* PW_G_WORDS, plus the diagnostic words of PW_STATS builds */
+    if (threadIdx.x == 0u) *frame = fr;
 }
 
 /* every tile rendered and no arena overflow: publish the cast count; else raise the flag the fallback launch looks at */
@@ -658,9 +696,9 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
     g_pw_last = pp;
     g_pw_last_groups = workgroups;
 #endif
-    hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global);
+    hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     record_main_kernel_event(0, stream);
-    hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PW_THREADS), 0, stream, sc, fr, pp, out);
+    hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PW_THREADS), 0, stream, sc, pp, out);
     record_main_kernel_event(1, stream);
     hipLaunchKernelGGL(pwf_finish_kernel, dim3(1), dim3(1), 0, stream, pp.global, fr.n_chunks, ray_count);
     return hipGetLastError();

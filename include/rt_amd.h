@@ -250,7 +250,8 @@ int rt_get_variant(void);
 /* Persistent-wavefront path (variant bit 4): size of its arenas, in ray_trace activations per tile pixel (default 6,
  * RT_AMD_WF_NODES_PER_PIXEL; the reference scene needs 3.4 at depth 8; about 200 B of device memory each, rounded up
  * to a power of two per workgroup).  A frame that needs more is detected on the device and rendered by the per-pixel
- * kernel within the same call, so the budget changes speed and memory only, never results. */
+ * kernel within the same call, so the budget changes speed and memory only, never results.  Arenas are never smaller
+ * than 1.5 MB per workgroup unless the budget is below 4. */
 int rt_set_wavefront_budget(unsigned nodes_per_pixel);
 
 /* Two-phase (variant 6) tuning: a tile wave parks its remaining lanes once at most `threshold` (0..63) are active

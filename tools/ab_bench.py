@@ -30,12 +30,13 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--world", type=int, default=1, help="render only rank 0's interleaved row band of this many ranks (a multi-GPU share)")
 args = ap.parse_args()
 
 world = rt.reference_world()
 cam = rt.reference_camera()
 desc = world.desc()
-frame = rt.Frame.full(args.width, args.height, args.depth)
+frame = rt.Frame.full(args.width, args.height, args.depth) if args.world == 1 else rt.Frame.rows_of_rank(args.width, args.height, args.depth, 0, args.world)
 libs = {}
 for tag in args.tags.split(","):
     parts = tag.split(":")  # "name", "name:variant", "name:variant:evict_threshold:evict_min_iter" or "name:variant:ENV=value[;ENV=value]"

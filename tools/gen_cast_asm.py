@@ -22,15 +22,17 @@ only consumed by SALU (interlocked) and branches use SCC, never VCCZ/EXECZ.
 """
 
 # ---- operand map of the asm statement (see cast_asm() in rt_cast.h) ----
-OUT = {"best_t": 0, "best_prim": 1}
-TEMPS = {f"r{k}": 2 + k for k in range(13)}
-IN = {"ox": 15, "oy": 16, "oz": 17, "dx": 18, "dy": 19, "dz": 20, "exid": 21, "keep_back": 22, "keep_front": 23,
-      "ex_if_back": 24, "ex_if_front": 25, "ptr": 26, "n": 27, "filter_ok": 28}
+# outputs: the nearest accepted hit so far: t, triangle index, and what the reference keeps of it — n.d (its sign is the
+# backface flag) and the three signed areas (the barycentric numerators), exactly the values the accept was decided on
+OUT = {"best_t": 0, "best_prim": 1, "best_nd": 2, "best_a0": 3, "best_a1": 4, "best_a2": 5}
+TEMPS = {f"r{k}": 6 + k for k in range(14)}
+_IN_NAMES = ["ox", "oy", "oz", "dx", "dy", "dz", "exid", "keep_back", "keep_front", "ex_if_back", "ex_if_front", "ptr", "n", "filter_ok"]
+IN = {name: 20 + k for k, name in enumerate(_IN_NAMES)}
 
 import sys
 COUNT = "--count-stages" in sys.argv  # diagnostic build (RT_DIAG_STAGES): eight extra "+v" operands count how far each triangle test got
 if COUNT:
-    TEMPS.update({f"c{k}": 15 + k for k in range(8)})
+    TEMPS.update({f"c{k}": 20 + k for k in range(8)})
     IN = {k: v + 8 for k, v in IN.items()}
 EARLY_AREA_EXITS = "--no-early-area-exits" not in sys.argv
 OUT_OF_LINE_EXCLUSION = "--inline-exclusion" not in sys.argv
@@ -107,8 +109,8 @@ def test(buf, label_next):
     n = (T["nx"], T["ny"], T["nz"])
     d = (op("dx"), op("dy"), op("dz"))
     o = (op("ox"), op("oy"), op("oz"))
-    r = [op(f"r{k}") for k in range(13)]
-    nd, num = r[11], r[12]  # num becomes t
+    r = [op(f"r{k}") for k in range(14)]
+    nd, num = r[13], r[12]  # num becomes t; nd stays live to the accept
     t = num
     L = []
     cnt = (lambda k: [f"v_add_u32 {op('c%d' % k)}, 1, {op('c%d' % k)}"]) if COUNT else (lambda k: [])
@@ -218,7 +220,8 @@ def test(buf, label_next):
     # accept for the lanes in alive
     L += cnt(6)
     L += [f"s_mov_b64 {S_EXSAVE}, exec", f"s_mov_b64 exec, {S_ALIVE}",
-          f"v_mov_b32 {op('best_t')}, {t}", f"v_mov_b32 {op('best_prim')}, {S_I}",
+          f"v_mov_b32 {op('best_t')}, {t}", f"v_mov_b32 {op('best_prim')}, {S_I}", f"v_mov_b32 {op('best_nd')}, {nd}",
+          f"v_mov_b32 {op('best_a0')}, {r[6]}", f"v_mov_b32 {op('best_a1')}, {r[7]}", f"v_mov_b32 {op('best_a2')}, {r[8]}",
           f"s_mov_b64 exec, {S_EXSAVE}"]
     return L
 
