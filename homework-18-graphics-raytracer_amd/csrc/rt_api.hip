@@ -56,6 +56,8 @@ struct rt_scene {
 
 static int g_evict_threshold = -1, g_evict_min_iter = -1;
 static int g_wf_nodes_per_pixel = -1;
+static const uint32_t *g_diag_tile_order = nullptr;
+extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order = static_cast<const uint32_t *>(device_ptr); }
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
@@ -483,6 +485,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 RT_HIP(hipMalloc(&ws.d_pwf, need));
                 ws.pwf_bytes = need;
             }
+            pw.tile_order = g_diag_tile_order;
             pw.global = static_cast<uint32_t *>(ws.d_pwf);
             pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 128);
             static_assert(sizeof(rt::KernelFrame) <= 128, "the frame description must fit its slot of the workspace header");

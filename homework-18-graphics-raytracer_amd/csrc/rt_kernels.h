@@ -105,6 +105,7 @@ struct PwParams {
     uint32_t ring_cap;      /* power of two >= node_cap + 1024: items of the shade and refraction rings */
     uint32_t tile_reserve;  /* nodes an arena must have free per primary ray before it takes more tiles */
     uint32_t tile_stride;   /* the k-th tile handed out is (k * tile_stride) mod n_tiles; coprime to n_tiles */
+    const uint32_t *tile_order; /* or, when set, tile_order[k] (n_tiles entries, a permutation) */
 };
 uint32_t pwf_threads();
 int pwf_workgroups_per_cu();

@@ -555,7 +555,9 @@ __global__ __launch_bounds__(PW_THREADS, PW_MIN_WAVES) void pwf_kernel(const Ker
             if (fetch_need != 0u) {
                 const uint32_t got = fetch_first >= n_tiles ? 0u : (n_tiles - fetch_first < fetch_need ? n_tiles - fetch_first : fetch_need);
                 /* consecutive fetches land far apart in the image (tile_stride is coprime to n_tiles) */
-                if (lane < got) S.tile_buf[lane] = (uint32_t)(((unsigned long long)(fetch_first + lane) * pp.tile_stride) % n_tiles);
+                if (lane < got)
+                    S.tile_buf[lane] = pp.tile_order != nullptr ? pp.tile_order[fetch_first + lane]
+                                                                : (uint32_t)(((unsigned long long)(fetch_first + lane) * pp.tile_stride) % n_tiles);
                 if (lane == 0u) {
                     S.tiles_seen = fetch_first + fetch_need;
                     S.tile_count = got;
