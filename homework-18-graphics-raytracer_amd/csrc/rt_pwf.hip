@@ -38,6 +38,7 @@
 #include "rt_shade.h"
 #include "rt_kernels.h"
 #include "rt_cast.h"
+#include "rt_pwf_common.h"
 
 namespace rt {
 
@@ -54,13 +55,6 @@ namespace rt {
 #define PW_PENDING_CHUNKS 12u /* a workgroup takes new tiles only while fewer chunks than this are queued: tiles must last
                                            * to the end of the frame, or the workgroups that met the expensive ones finish long after the rest */
 #endif
-#define PW_NO_CHILD 0xffffffffu
-#define PW_FINAL 0xfffffffeu  /* record.cr: the stored value is final (miss, or the unscaled shade at depth 0) */
-/* the exclusion word of a queued ray also carries: bits 21-26 the depth left for the node, bits 27-28 the ray's face mode */
-#define PW_DEPTH_SHIFT 21u
-#define PW_MODE_SHIFT 27u
-#define PW_EXCL_MASK (0xe0000000u | ((1u << PW_DEPTH_SHIFT) - 1u))
-
 #ifndef PW_MIN_WAVES
 #define PW_MIN_WAVES 6
 #endif
@@ -79,44 +73,6 @@ struct PwShared {
     uint32_t next_chunk;               /* chunks of the running iteration handed out so far */
     uint32_t tiles_seen;               /* the frame-wide tile counter as of this workgroup's last fetch */
 };
-
-__device__ __forceinline__ uint32_t pfu(float x) { return __float_as_uint(x); }
-__device__ __forceinline__ float puf(uint32_t x) { return __uint_as_float(x); }
-
-/* wave-aggregated reservation on an LDS counter: lanes with `want` get consecutive positions */
-__device__ __forceinline__ uint32_t lds_append(uint32_t *counter, bool want) {
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0ull) return 0u;
-    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
-    const int leader = (int)__builtin_ctzll(mask);
-    uint32_t base = 0u;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, n);
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-__device__ __forceinline__ void pw_slot_to_pixel(const KernelFrame &fr, uint32_t slot, uint32_t *row, uint32_t *col) {
-    const uint32_t band_slots = fr.cols << 3;
-    const uint32_t band = slot / band_slots;
-    const uint32_t r = slot - band * band_slots;
-    const uint32_t rows_left = fr.rows - (band << 3);
-    const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
-    *col = r / band_rows;
-    *row = (band << 3) + (r - *col * band_rows);
-}
-
-/* get_shade's `for light in &self.lights` up to the next shadow cast (main.rs:413-433): advance *light_i to the first
- * light from *light_i on that needs one; false when the loop is over */
-__device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t *light_i, V3 pos, V3 adj_n, DirLight *dl) {
-    while (*light_i < sc.n_lights) {
-        if (approximate_into_directional(sc.lights[*light_i], pos, dl)) {
-            const float cosine = -dot(dl->direction, adj_n);
-            if (!(cosine <= 0.0f)) return true;
-        }
-        *light_i += 1u;
-    }
-    return false;
-}
 
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read twice per tile, and as
  * a by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
@@ -689,7 +645,7 @@ extern "C" int rt_diag_read_pwf(uint32_t *out32) {
 #endif
 
 hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream) {
+                      uint32_t workgroups, hipStream_t stream, bool async) {
     const uint32_t total = fr.cols * fr.rows;
     fr.n_chunks = (total + 63u) / 64u;
     if (total == 0u) return hipSuccess;
@@ -700,7 +656,10 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
 #endif
     hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     record_main_kernel_event(0, stream);
-    hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PW_THREADS), 0, stream, sc, pp, out);
+    if (async)
+        launch_pwf_async_main(sc, pp, out, workgroups, stream);
+    else
+        hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PW_THREADS), 0, stream, sc, pp, out);
     record_main_kernel_event(1, stream);
     hipLaunchKernelGGL(pwf_finish_kernel, dim3(1), dim3(1), 0, stream, pp.global, fr.n_chunks, ray_count);
     return hipGetLastError();

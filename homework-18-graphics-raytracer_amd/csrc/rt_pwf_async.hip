@@ -1,0 +1,625 @@
+/*
+ * rt_pwf_async.hip — the persistent workgroup-local wavefront kernel without barriers (RT_VARIANT_PWF_ASYNC).
+ *
+ * Same work items, arenas and arithmetic as rt_pwf.hip (read that file's header first).  What differs is how a
+ * workgroup's eight waves share its three queues.  There, iterations are separated by two barriers and an item made in
+ * one iteration can be picked up in the next at the earliest — a dependent chain (a ray_trace activation, its
+ * refraction casts, its child, ...) advances one step per iteration, ~45 us when the machine is full, and the waves of a
+ * workgroup wait for its slowest chunk every time.  Here every wave loops on its own:
+ *
+ *   claim a page (64 consecutive queue positions) of NODE, else REFR items; else start a fresh tile; else a page of
+ *   SHADE items; else a partly filled page; else sleep a little and look again
+ *
+ * so a chain advances as fast as single chunks take, and nobody waits for anybody.  The bookkeeping that makes this
+ * safe, all in LDS:
+ *
+ *   - producers reserve positions with one wave-aggregated atomic on `alloc`, write their items, fence, and then add
+ *     the number written to `ready[page]` (an item range may straddle two pages);
+ *   - consumers claim pages in order with a compare-and-swap on `taken`; a page may be claimed when its ready count is
+ *     64, or when it has been SEALED: a consumer that finds only a partly filled last page, all of whose reserved
+ *     positions are written, moves `alloc` to the next page boundary (compare-and-swap, so no reservation can slip in)
+ *     and marks the page sealed with the count it had;
+ *   - a wave that finds nothing at all counts itself idle; when all eight are idle at once nobody can produce anything
+ *     any more (only a running wave makes items or fetches tiles) and the loop ends.  A wave stops being idle BEFORE it
+ *     looks for work, so "all idle" cannot be seen while somebody is about to claim.
+ *
+ * No wave ever waits for a particular other wave, so there is nothing to deadlock on; an (unreachable) spin limit turns
+ * a would-be hang into the overflow fallback.  Root nodes (primary rays) are made in registers and cast at once; their
+ * ids come from the top of the arena so that they do not appear in the NODE queue, whose positions are node ids.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_amd.h"
+#include "rt_device_scene.h"
+#include "rt_shade.h"
+#include "rt_kernels.h"
+#include "rt_cast.h"
+#include "rt_pwf_common.h"
+
+namespace rt {
+
+#define PA_WAVES 8u
+#define PA_THREADS (PA_WAVES * 64u)
+#ifndef PA_MIN_WAVES
+#define PA_MIN_WAVES 6
+#endif
+#ifndef PA_SHADE_PAGES
+#define PA_SHADE_PAGES 8u /* a wave starts a fresh tile rather than a SHADE page while fewer SHADE pages than this are queued */
+#endif
+#ifndef PA_MIN_PARTIAL
+#define PA_MIN_PARTIAL 32u
+#endif
+#define PA_SEALED 0x80000000u
+#define PA_SPIN_LIMIT (1u << 22)
+
+enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u };
+
+struct PaQueue {
+    uint32_t alloc; /* next position to reserve */
+    uint32_t taken; /* next PAGE to claim */
+};
+
+struct PaShared {
+    PaQueue n, f, s;          /* NODE (positions are node ids), REFR ring, SHADE ring */
+    uint32_t root_alloc;      /* root nodes, handed out from the top of the arena downwards */
+    uint32_t tiles_exhausted; /* the frame-wide counter ran out, or this arena has no room for another tile */
+    uint32_t tile_list_count;
+    uint32_t idle;            /* waves asleep: they found nothing and wait for `gen` to move */
+    uint32_t gen;             /* bumped whenever items are published */
+    uint32_t done;            /* all waves idle at once: the queues are final */
+    uint32_t abort;
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+/* lane 0 only.  Try to claim the next page of a queue; on success *start is its first position and the return value its
+ * item count.  ready[] holds one word per page (index masked for the rings). */
+__device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
+    for (int tries = 0; tries < 4; ++tries) {
+        const uint32_t page = lds_load(&q->taken);
+        const uint32_t a = lds_load(&q->alloc);
+        if (a <= page * 64u) return 0u; /* empty */
+        const uint32_t w = lds_load(&ready[page & page_mask]);
+        const uint32_t c = w & 0xffffu;
+        if (c == 64u || (w & PA_SEALED) != 0u) {
+            if (atomicCAS(&q->taken, page, page + 1u) == page) {
+                ready[page & page_mask] = 0u; /* the slot is reused one lap later at the earliest */
+                *start = page * 64u;
+                return c;
+            }
+            continue; /* somebody else took it: look at the next page */
+        }
+        if (min_partial == 0u || a >= (page + 1u) * 64u || c < min_partial || c != a - page * 64u) return 0u; /* still filling */
+        /* a partly filled last page whose reserved positions are all written: close it against further reservations */
+        if (atomicCAS(&q->alloc, a, (page + 1u) * 64u) == a) atomicOr(&ready[page & page_mask], PA_SEALED);
+    }
+    return 0u;
+}
+
+/* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
+__device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the items are written before they are counted */
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const int leader = (int)__builtin_ctzll(mask);
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader); /* the leader holds the lowest position */
+    if ((int)(threadIdx.x & 63u) == leader) {
+        const uint32_t p0 = first >> 6, p1 = (first + n - 1u) >> 6;
+        if (p0 == p1) {
+            atomicAdd(&ready[p0 & page_mask], n);
+        } else {
+            const uint32_t n0 = (p1 << 6) - first;
+            atomicAdd(&ready[p0 & page_mask], n0);
+            atomicAdd(&ready[p1 & page_mask], n - n0);
+        }
+        atomicAdd(gen, 1u); /* wakes the sleepers */
+    }
+}
+
+__global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_async_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
+    extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
+    __shared__ PaShared S;
+    const KernelFrame &fr = *pp.frame;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_slots = fr.cols * fr.rows;
+    const uint32_t n_tiles = fr.n_chunks;
+    const float THRESHOLD = 0.001f; /* main.rs:467 */
+
+    /* this workgroup's arena (layout as in rt_pwf.hip) */
+    unsigned char *arena = pp.arena + (size_t)blockIdx.x * pp.arena_stride;
+    uint4 *node_in = reinterpret_cast<uint4 *>(arena);
+    uint4 *nodes = node_in + (size_t)pp.node_cap * 2u;
+    uint4 *shade_q = nodes + (size_t)pp.node_cap * 2u;
+    uint4 *refr_q = shade_q + (size_t)pp.ring_cap * 5u;
+    uint32_t *tile_list = reinterpret_cast<uint32_t *>(refr_q + (size_t)pp.ring_cap * 3u);
+    const uint32_t ring_mask = pp.ring_cap - 1u;
+    const uint32_t tile_cap = pp.node_cap / 64u;
+    const uint32_t node_pages = (pp.node_cap + 63u) / 64u, ring_pages = pp.ring_cap / 64u;
+    uint32_t *ready_n = pa_ready, *ready_s = pa_ready + node_pages, *ready_f = ready_s + ring_pages;
+    const uint32_t ring_page_mask = ring_pages - 1u;
+
+    for (uint32_t i = threadIdx.x; i < node_pages + 2u * ring_pages; i += PA_THREADS) pa_ready[i] = 0u;
+    if (threadIdx.x == 0u) {
+        S.n.alloc = S.n.taken = 0u;
+        S.f.alloc = S.f.taken = 0u;
+        S.s.alloc = S.s.taken = 0u;
+        S.root_alloc = 0u;
+        S.tiles_exhausted = 0u;
+        S.tile_list_count = 0u;
+        S.idle = 0u;
+        S.gen = 0u;
+        S.done = 0u;
+        S.abort = 0u;
+    }
+    __syncthreads();
+    uint32_t casts = 0u;
+
+    for (;;) {
+        if (lds_load(&S.done) != 0u || lds_load(&S.abort) != 0u) break;
+
+        /* ---- find work (lane 0 decides, the wave follows) ---- */
+        uint32_t type = PA_T_NONE, start = 0u, count = 0u;
+        if (lane == 0u) {
+            const uint32_t gen = lds_load(&S.gen); /* before looking: a publish during the look must not be slept through */
+            count = pa_claim(&S.n, ready_n, 0xffffffffu, 0u, &start);
+            if (count != 0u) type = PA_T_NODE;
+            if (type == PA_T_NONE) {
+                count = pa_claim(&S.f, ready_f, ring_page_mask, 0u, &start);
+                if (count != 0u) type = PA_T_REFR;
+            }
+            bool tried_tile = false;
+            for (int pass = 0; pass < 2 && type == PA_T_NONE; ++pass) {
+                /* a fresh tile: before SHADE work while little of it is queued (pass 0), else after the full pages (pass 1) */
+                if (!tried_tile && lds_load(&S.tiles_exhausted) == 0u) {
+                    const uint32_t shade_pages = (lds_load(&S.s.alloc) >> 6) - lds_load(&S.s.taken);
+                    if (pass == 1 || (int32_t)shade_pages < (int32_t)PA_SHADE_PAGES) {
+                        tried_tile = true;
+                        const uint32_t used = lds_load(&S.n.alloc) + lds_load(&S.root_alloc);
+                        const uint32_t room = pp.node_cap > used ? pp.node_cap - used : 0u;
+                        if (room < 64u * pp.tile_reserve || lds_load(&S.tile_list_count) >= tile_cap) {
+                            S.tiles_exhausted = 1u; /* this arena is nearly full: the other workgroups take the rest */
+                        } else {
+                            const uint32_t k = atomicAdd(pp.global + PW_G_TILE, 1u);
+                            if (k >= n_tiles) {
+                                S.tiles_exhausted = 1u;
+                            } else {
+                                /* consecutive fetches land far apart in the image (tile_stride is coprime to n_tiles) */
+                                start = pp.tile_order != nullptr ? pp.tile_order[k] : (uint32_t)(((unsigned long long)k * pp.tile_stride) % n_tiles);
+                                count = total_slots - start * 64u < 64u ? total_slots - start * 64u : 64u;
+                                type = PA_T_TILE;
+                            }
+                        }
+                    }
+                }
+                if (type == PA_T_NONE && pass == 0) {
+                    count = pa_claim(&S.s, ready_s, ring_page_mask, 0u, &start);
+                    if (count != 0u) type = PA_T_SHADE;
+                }
+            }
+            /* Partly filled pages: waiting for them to fill would hold up the chains behind their items, but a page taken
+             * with a handful of items costs a full intersection loop.  Half a page at least while other waves are awake
+             * and may add to it; anything once this wave is the last one awake (then nobody will). */
+            for (int last = 0; last < 2 && type == PA_T_NONE; ++last) {
+                const uint32_t min_partial = last ? 1u : PA_MIN_PARTIAL;
+                count = pa_claim(&S.n, ready_n, 0xffffffffu, min_partial, &start);
+                if (count != 0u) { type = PA_T_NODE; break; }
+                count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
+                if (count != 0u) { type = PA_T_REFR; break; }
+                count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
+                if (count != 0u) { type = PA_T_SHADE; break; }
+                if (last) {
+                    /* the last wave awake found nothing whatsoever: the queues are final.  (Idle waves stay counted while
+                     * they sleep, so the count is still PA_WAVES - 1 unless one has just been woken by new items.) */
+                    if (lds_load(&S.idle) == PA_WAVES - 1u) S.done = 1u;
+                    break;
+                }
+                /* count this wave idle; if that makes all of them, it is the last one awake: look once more, for anything */
+                if (atomicAdd(&S.idle, 1u) + 1u == PA_WAVES) {
+                    atomicSub(&S.idle, 1u);
+                    continue;
+                }
+                /* sleep until somebody publishes items (or everything is over), then look again */
+                uint32_t spins = 0u;
+                while (lds_load(&S.gen) == gen && lds_load(&S.done) == 0u && lds_load(&S.abort) == 0u) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > PA_SPIN_LIMIT) { /* cannot happen; a hang would cost a GPU, the fallback only a frame */
+                        S.abort = 1u;
+                        atomicExch(pp.global + PW_G_OVERFLOW, 1u);
+                    }
+                }
+                atomicSub(&S.idle, 1u);
+                break;
+            }
+        }
+        type = (uint32_t)__builtin_amdgcn_readfirstlane((int)type);
+        start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
+        if (type == PA_T_NONE) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the page's items were written before they were counted */
+
+        /* ---- load the chunk's items and set up their rays ---- */
+        const bool active = lane < count;
+        Ray req;
+        req.o = v3(0.0f, 0.0f, 0.0f);
+        req.d = v3(0.0f, 0.0f, 1.0f);
+        req.mode = FACE_FRONT;
+        req.excl = 0u;
+        bool do_cast = active;
+        uint32_t id = 0u;            /* NODE: this node; REFR: the parent node; SHADE: the shaded node */
+        uint32_t depth = 0u;         /* NODE: depth left for this node; REFR: depth left for the escape child */
+        float contribution = 1.0f;   /* NODE: contribution; REFR: the child's contribution */
+        uint32_t obj = 0u;           /* REFR, SHADE */
+        float travel = 0.0f;         /* REFR */
+        int32_t retry = -1;          /* REFR: -1 = the pending cast is the first inside cast (main.rs:371) */
+        uint32_t prim = 0u, light_i = 0u, sflags = 0u; /* SHADE */
+        V3 spos = v3(0.0f, 0.0f, 0.0f), adj_n = v3(0.0f, 0.0f, 1.0f), in_dir = v3(0.0f, 0.0f, 1.0f), sdiffuse = spos, sum = spos;
+        DirLight dl;
+        dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
+
+        if (type == PA_T_TILE) {
+            /* main.rs:1093-1100: the tile's primary rays are root nodes (depth max_depth, contribution 1.0), cast right away */
+            const uint32_t tile = start;
+            uint32_t base = 0u, entry = 0u;
+            if (lane == 0u) {
+                base = atomicAdd(&S.root_alloc, count);
+                entry = atomicAdd(&S.tile_list_count, 1u);
+            }
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry);
+            if (base + count + lds_load(&S.n.alloc) > pp.node_cap || entry >= tile_cap) { /* the reserve makes this unreachable; be safe */
+                if (lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
+                break;
+            }
+            const uint32_t first_id = pp.node_cap - base - count; /* roots fill the arena from the top */
+            if (lane == 0u) { tile_list[entry * 2u] = tile; tile_list[entry * 2u + 1u] = first_id; }
+            id = first_id + lane;
+            depth = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0);
+            if (active) {
+                uint32_t row, col;
+                pw_slot_to_pixel(fr, tile * 64u + lane, &row, &col);
+                /* Camera::shoot (main.rs:84-99), per-frame basis hoisted to the host */
+                const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+                const float clip_y = (fr.half_height - (float)y) / fr.height_f;
+                const float clip_x = ((float)x - fr.half_width) / fr.height_f;
+                const V3 cx = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
+                const V3 cy = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
+                const V3 ct = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
+                req.o = v3(fr.cam_origin[0], fr.cam_origin[1], fr.cam_origin[2]);
+                req.d = normalize(clip_x * cx + clip_y * cy + ct);
+            }
+            type = PA_T_NODE;
+        } else if (type == PA_T_NODE) {
+            id = start + lane;
+            /* a sealed page: the positions after its last item are node ids nobody owns; the fold walks all ids below
+             * n.alloc, so they must not look like nodes (depth 0 is never folded) */
+            if (!active && id < pp.node_cap) reinterpret_cast<uint32_t *>(node_in + (size_t)id * 2u + 1u)[2] = 0u;
+            if (active) {
+                const uint4 a = node_in[(size_t)id * 2u], b = node_in[(size_t)id * 2u + 1u];
+                req.o = v3(puf(a.x), puf(a.y), puf(a.z));
+                req.d = v3(puf(a.w), puf(b.x), puf(b.y));
+                req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
+                depth = (b.z >> PW_DEPTH_SHIFT) & 63u;
+                req.excl = b.z & PW_EXCL_MASK;
+                contribution = puf(b.w);
+            }
+        } else if (type == PA_T_REFR) {
+            if (active) {
+                const uint4 *t = refr_q + (size_t)((start + lane) & ring_mask) * 3u;
+                const uint4 a = t[0], b = t[1], c = t[2];
+                req.o = v3(puf(a.x), puf(a.y), puf(a.z));
+                req.d = v3(puf(a.w), puf(b.x), puf(b.y));
+                req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
+                depth = (b.z >> PW_DEPTH_SHIFT) & 63u;
+                req.excl = b.z & PW_EXCL_MASK;
+                id = b.w;
+                obj = c.x;
+                contribution = puf(c.y);
+                travel = puf(c.z);
+                retry = (int32_t)c.w;
+            }
+        } else { /* PA_T_SHADE */
+            if (active) {
+                const uint4 *t = shade_q + (size_t)((start + lane) & ring_mask) * 5u;
+                const uint4 a = t[0], b = t[1], c = t[2], d = t[3], e = t[4];
+                id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
+                spos = v3(puf(b.x), puf(b.y), puf(b.z)); sum.x = puf(b.w);
+                adj_n = v3(puf(c.x), puf(c.y), puf(c.z)); sum.y = puf(c.w);
+                in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
+                sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z));
+                do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl); /* always true for a queued item */
+                req.o = spos;
+                req.d = -dl.direction;
+                req.mode = FACE_BACK;
+                req.excl = pack_excl(prim, FACE_BACK);
+            }
+        }
+
+        /* ---- the cast: the one place the intersection loop is instantiated ---- */
+        CastResult cr;
+        cr.prim = -1;
+        cr.t = 0.0f;
+        cr.bf = 0u;
+        cr.a0 = cr.a1 = cr.a2 = 0.0f;
+        if (do_cast) {
+            cr = cast_asm(sc, req);
+            casts += 1u;
+        }
+
+        if (type == PA_T_NODE) {
+            /* ---- ray_trace after its cast (main.rs:475-505) ---- */
+            V3 acc = v3(0.0f, 0.0f, 0.0f);
+            float rc = 0.0f, fc = 0.0f;
+            uint32_t rec_cr = PW_FINAL, rec_cf = PW_NO_CHILD; /* a miss is black and final (main.rs:475) */
+            bool want_shade = false, want_refl = false, want_refr = false;
+            HitGeom nh;
+            nh.pos = nh.normal = v3(0.0f, 0.0f, 0.0f);
+            nh.u = nh.v = 0.0f;
+            nh.prim = nh.bf = nh.obj = 0u;
+            V3 inside_d = v3(0.0f, 0.0f, 0.0f);
+            if (active && cr.prim >= 0) {
+                nh = finish_hit(sc, req, cr, false);
+                const rt_material &rm = sc.materials[nh.obj];
+                const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                want_shade = contribution * shade_contribution >= THRESHOLD; /* main.rs:480-483 */
+                if (depth > 0u) {
+                    acc = v3(0.0f, 0.0f, 0.0f) * shade_contribution; /* black * shade_contribution unless a SHADE item fills it in */
+                    rc = rm.shiness * (1.0f - rm.transparency);      /* main.rs:493 */
+                    fc = rm.transparency;                            /* main.rs:502 */
+                    rec_cr = PW_NO_CHILD;
+                    want_refl = contribution * rc >= THRESHOLD;      /* main.rs:494-495 */
+                    if (contribution * fc > THRESHOLD) {             /* main.rs:502-505, strict */
+                        V3 refract_in;
+                        if (refract_dir(nh.normal, req.d, rm.refraction_index, &refract_in)) { /* else Trapped */
+                            inside_d = normalize(refract_in);        /* second normalize, main.rs:362 */
+                            want_refr = true;
+                        }
+                    }
+                }
+                /* depth == 0 (main.rs:488-490): the value is the unscaled shade */
+                if (want_shade) {
+                    const Mat m = material_approx(rm, nh.u, nh.v);
+                    adj_n = adjust_normal(m.normal, nh.normal); /* main.rs:410 */
+                    sdiffuse = m.diffuse;
+                    light_i = 0u;
+                    want_shade = next_shadow_ray(sc, &light_i, nh.pos, adj_n, &dl); /* no light needs a cast: get_shade = black */
+                }
+            }
+            /* the record first: REFR items refer to it, and its children are written into it below */
+            const uint32_t k_refl = lds_append(&S.n.alloc, want_refl);
+            const bool overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
+            if (want_refl && !overflow) rec_cr = k_refl;
+            if (active) {
+                nodes[(size_t)id * 2u] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
+                nodes[(size_t)id * 2u + 1u] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
+            }
+            /* reflection child (get_reflect, main.rs:328-341) */
+            if (want_refl && !overflow) {
+                const V3 d = reflect_dir(nh.normal, req.d);
+                const uint32_t word = pack_excl(nh.prim, nh.bf ? FACE_FRONT : FACE_BACK) | (req.mode << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
+                node_in[(size_t)k_refl * 2u] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(d.x));
+                node_in[(size_t)k_refl * 2u + 1u] = make_uint4(pfu(d.y), pfu(d.z), word, pfu(contribution * rc));
+            }
+            /* the first shadow cast of get_shade */
+            const uint32_t k_shade = lds_append(&S.s.alloc, want_shade);
+            if (want_shade) {
+                uint4 *t = shade_q + (size_t)(k_shade & ring_mask) * 5u;
+                t[0] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), 0u);
+                t[1] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(0.0f));
+                t[2] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(0.0f));
+                t[3] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
+                t[4] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+            }
+            /* the ray into the glass (main.rs:358-366) */
+            const uint32_t k_refr = lds_append(&S.f.alloc, want_refr);
+            if (want_refr) {
+                uint4 *t = refr_q + (size_t)(k_refr & ring_mask) * 3u;
+                const uint32_t word = pack_excl(nh.prim, FACE_FRONT) | (FACE_BACK << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
+                t[0] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(inside_d.x));
+                t[1] = make_uint4(pfu(inside_d.y), pfu(inside_d.z), word, id);
+                t[2] = make_uint4(nh.obj, pfu(contribution * fc), pfu(0.0f), 0xffffffffu);
+            }
+            /* everything is written: count it in */
+            const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull; /* then the frame is abandoned: nothing to count in */
+            pa_publish(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
+            pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
+            pa_publish(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
+            if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
+        } else if (type == PA_T_REFR) {
+            /* ---- one step of get_refract (main.rs:371-403) ---- */
+            bool requeue = false, escape = false;
+            V3 esc_o = v3(0.0f, 0.0f, 0.0f), esc_d = esc_o;
+            uint32_t esc_excl = 0u;
+            float decay = 0.0f;
+            if (active && cr.prim >= 0) { /* a miss is Refraction::Infinite (main.rs:373, 383): no child */
+                const HitGeom ih = finish_hit(sc, req, cr, false);
+                if (retry < 0) {
+                    travel = distance(ih.pos, req.o); /* main.rs:375; req.o is the node's hit position */
+                    retry = 0;
+                } else {
+                    travel += distance(req.o, ih.pos); /* main.rs:385; req.o is the previous inside hit */
+                    retry += 1;
+                }
+                const rt_material &rm = sc.materials[obj];
+                V3 out_dir;
+                const bool have_out = refract_dir(ih.normal, req.d, 1.0f / rm.refraction_index, &out_dir);
+                if (!have_out && travel <= 100.0f && retry < 10) { /* main.rs:378 */
+                    /* get_reflect(&hit_inside), main.rs:328-341; the bounce keeps the ray's face mode */
+                    const V3 d = reflect_dir(ih.normal, req.d);
+                    req.o = ih.pos;
+                    req.d = d;
+                    req.excl = pack_excl(ih.prim, ih.bf ? FACE_FRONT : FACE_BACK);
+                    requeue = true;
+                } else if (have_out) { /* Escaped, main.rs:392-403; else Trapped */
+                    escape = true;
+                    esc_o = ih.pos;
+                    esc_d = normalize(out_dir);
+                    esc_excl = pack_excl(ih.prim, FACE_BACK);
+                    decay = rtdm::powf(rm.opaque_decay, travel); /* main.rs:508 */
+                }
+            }
+            const uint32_t k_again = lds_append(&S.f.alloc, requeue);
+            if (requeue) {
+                uint4 *t = refr_q + (size_t)(k_again & ring_mask) * 3u;
+                const uint32_t word = req.excl | (req.mode << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
+                t[0] = make_uint4(pfu(req.o.x), pfu(req.o.y), pfu(req.o.z), pfu(req.d.x));
+                t[1] = make_uint4(pfu(req.d.y), pfu(req.d.z), word, id);
+                t[2] = make_uint4(obj, pfu(contribution), pfu(travel), (uint32_t)retry);
+            }
+            const uint32_t k_child = lds_append(&S.n.alloc, escape);
+            const bool overflow = escape && k_child + lds_load(&S.root_alloc) >= pp.node_cap;
+            if (escape && !overflow) {
+                const uint32_t word = esc_excl | (FACE_FRONT << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
+                node_in[(size_t)k_child * 2u] = make_uint4(pfu(esc_o.x), pfu(esc_o.y), pfu(esc_o.z), pfu(esc_d.x));
+                node_in[(size_t)k_child * 2u + 1u] = make_uint4(pfu(esc_d.y), pfu(esc_d.z), word, pfu(contribution));
+                uint32_t *rec = reinterpret_cast<uint32_t *>(nodes + (size_t)id * 2u);
+                rec[5] = pfu(decay);
+                rec[7] = k_child;
+            }
+            const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull;
+            pa_publish(ready_f, ring_page_mask, requeue, k_again, &S.gen);
+            pa_publish(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
+            if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
+        } else {
+            /* ---- one light of get_shade (main.rs:435-461) ---- */
+            bool again = false;
+            if (active) {
+                const rt_material &rm = sc.materials[obj];
+                if (do_cast) {
+                    const rt_light &L = sc.lights[light_i];
+                    bool lit = true;
+                    if (cr.prim >= 0) {
+                        const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
+                        if (has_origin) {
+                            const V3 occ = req.o + req.d * cr.t;
+                            const float occlusion_distance = distance(spos, occ);
+                            const float light_distance = distance(spos, v3(L.origin[0], L.origin[1], L.origin[2]));
+                            if (occlusion_distance < light_distance) lit = false;
+                        } else {
+                            lit = false;
+                        }
+                    }
+                    if (lit) { /* main.rs:450-461 */
+                        Mat m;
+                        m.normal = v3(0.0f, 0.0f, 0.0f); /* already folded into adj_n */
+                        m.diffuse = sdiffuse;
+                        m.specular = v3(rm.specular_color[0], rm.specular_color[1], rm.specular_color[2]);
+                        m.shiness = rm.shiness;
+                        m.smoothness = rm.smoothness;
+                        m.transparency = rm.transparency;
+                        m.refraction_index = rm.refraction_index;
+                        m.opaque_decay = rm.opaque_decay;
+                        const V3 light_direction = req.d; /* = -light.direction */
+                        const V3 view_direction = -in_dir;
+                        const V3 diffuse = get_diffuse(m, adj_n, light_direction) * dl.color;
+                        const V3 specular = get_specular(m, adj_n, view_direction, light_direction) * dl.color;
+                        sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
+                    }
+                    light_i += 1u;
+                    again = next_shadow_ray(sc, &light_i, spos, adj_n, &dl);
+                }
+                if (!again) {
+                    V3 acc = sum; /* depth 0: the unscaled shade (main.rs:488-490) */
+                    if (sflags == 0u) {
+                        const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                        acc = sum * shade_contribution;
+                    }
+                    float *rec = reinterpret_cast<float *>(nodes + (size_t)id * 2u);
+                    rec[0] = acc.x;
+                    rec[1] = acc.y;
+                    rec[2] = acc.z;
+                }
+            }
+            const uint32_t k_again = lds_append(&S.s.alloc, again);
+            if (again) {
+                uint4 *t = shade_q + (size_t)(k_again & ring_mask) * 5u;
+                t[0] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), 0u);
+                t[1] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
+                t[2] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
+                t[3] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
+                t[4] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+            }
+            pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
+        }
+    }
+
+    /* ---- fold the records bottom-up (main.rs:516-518) and write the pixels ---- */
+    __syncthreads();
+    const bool aborted = S.abort != 0u;
+    const uint32_t n_nodes = S.n.alloc < pp.node_cap ? S.n.alloc : pp.node_cap; /* the queued nodes; roots sit at the top */
+    const uint32_t max_depth = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0);
+    if (!aborted) {
+        for (uint32_t left = 1u; left < max_depth; ++left) {
+            for (uint32_t id = threadIdx.x; id < n_nodes; id += PA_THREADS) {
+                const uint32_t word = reinterpret_cast<const uint32_t *>(node_in + (size_t)id * 2u + 1u)[2];
+                if (((word >> PW_DEPTH_SHIFT) & 63u) != left) continue;
+                const uint4 a = nodes[(size_t)id * 2u], b = nodes[(size_t)id * 2u + 1u];
+                if (b.z == PW_FINAL) continue;
+                const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
+                V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
+                if (b.z != PW_NO_CHILD) {
+                    const uint4 c = nodes[(size_t)b.z * 2u];
+                    reflection = v3(puf(c.x), puf(c.y), puf(c.z));
+                }
+                if (b.w != PW_NO_CHILD) {
+                    const uint4 c = nodes[(size_t)b.w * 2u];
+                    refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay; /* main.rs:508 */
+                }
+                const V3 value = (v3(puf(a.x), puf(a.y), puf(a.z)) + reflection * rc) + refraction * fc;
+                float *rec = reinterpret_cast<float *>(nodes + (size_t)id * 2u);
+                rec[0] = value.x;
+                rec[1] = value.y;
+                rec[2] = value.z;
+            }
+            __syncthreads();
+        }
+        const uint32_t n_started = S.tile_list_count;
+        for (uint32_t e = threadIdx.x >> 6; e < n_started; e += PA_WAVES) {
+            const uint32_t tile = tile_list[e * 2u], base = tile_list[e * 2u + 1u];
+            const uint32_t first_slot = tile * 64u;
+            const uint32_t nv = total_slots - first_slot < 64u ? total_slots - first_slot : 64u;
+            if (lane >= nv) continue;
+            const uint32_t id = base + lane;
+            const uint4 a = nodes[(size_t)id * 2u], b = nodes[(size_t)id * 2u + 1u];
+            V3 value = v3(puf(a.x), puf(a.y), puf(a.z));
+            if (b.z != PW_FINAL) {
+                const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
+                V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
+                if (b.z != PW_NO_CHILD) {
+                    const uint4 c = nodes[(size_t)b.z * 2u];
+                    reflection = v3(puf(c.x), puf(c.y), puf(c.z));
+                }
+                if (b.w != PW_NO_CHILD) {
+                    const uint4 c = nodes[(size_t)b.w * 2u];
+                    refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay;
+                }
+                value = (value + reflection * rc) + refraction * fc;
+            }
+            uint32_t row, col;
+            pw_slot_to_pixel(fr, first_slot + lane, &row, &col);
+            /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
+            float *px = out + ((size_t)row * fr.cols + col) * 3u;
+            px[0] = 0.0f + value.x;
+            px[1] = 0.0f + value.y;
+            px[2] = 0.0f + value.z;
+        }
+        if (threadIdx.x == 0u && n_started != 0u) atomicAdd(pp.global + PW_G_TILES_DONE, n_started);
+    }
+    for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
+    if (lane == 0u && casts != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), (unsigned long long)casts);
+}
+
+int pwf_async_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap) {
+    int n = 0;
+    const size_t lds = (size_t)((node_cap + 63u) / 64u + 2u * (ring_cap / 64u)) * sizeof(uint32_t);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_async_kernel, (int)PA_THREADS, lds) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+void launch_pwf_async_main(const KernelScene &sc, const PwParams &pp, float *out, uint32_t workgroups, hipStream_t stream) {
+    const size_t lds = (size_t)((pp.node_cap + 63u) / 64u + 2u * (pp.ring_cap / 64u)) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pwf_async_kernel, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+}
+
+} /* namespace rt */
