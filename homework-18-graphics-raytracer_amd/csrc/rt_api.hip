@@ -341,7 +341,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
     if (e != hipSuccess || cus <= 0) cus = 256;
     sc->resident_waves = (uint32_t)cus * 4u * (uint32_t)RT_MIN_WAVES;
-    sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu();
+    sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu(7168u, 8192u);
     *out_scene = sc;
     return RT_OK;
 }
@@ -463,9 +463,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             /* tiles are handed out dynamically, so a workgroup may end up with several times the average: arenas have a
              * floor of 8192 ring slots (1.5 MB) however small the frame (budgets below 4 waive it: tests of the fallback) */
             uint64_t ring = g_wf_nodes_per_pixel >= 4 ? 8192 : 2048;
-            /* (the barrier-free kernel keeps one LDS word per 64 ring slots: 64 K slots at most) */
-            const uint64_t ring_max = (variant & RT_VARIANT_PWF_ASYNC) ? (1ull << 16) : (1ull << 30);
-            while (ring < want + 1024u && ring < ring_max) ring <<= 1;
+            /* (the kernel keeps one LDS word per 64 ring slots and 64 nodes: 64 K slots at most) */
+            while (ring < want + 1024u && ring < (1ull << 16)) ring <<= 1;
             pw.ring_cap = (uint32_t)ring;
             pw.node_cap = (uint32_t)(ring - 1024u);
             /* (the budget sizes the rings; an arena may use all of its ring's worth of nodes: tiles are handed out
@@ -513,7 +512,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     }
     hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
     if (e == hipSuccess && (variant & RT_VARIANT_PWF)) {
-        e = rt::launch_pwf(scene->ks, kf, d_rgb, d_ray_count, pw, pw_groups, stream, (variant & RT_VARIANT_PWF_ASYNC) != 0);
+        e = rt::launch_pwf(scene->ks, kf, d_rgb, d_ray_count, pw, pw_groups, stream);
         /* a frame that did not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
         qs.run_if = pw.global + PW_G_OVERFLOW;
         variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;

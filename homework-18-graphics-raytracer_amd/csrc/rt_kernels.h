@@ -35,8 +35,7 @@
 #define RT_VARIANT_COOP 8         /* bit 3: cooperative workgroups — four waves split every tile's triangle loop */
 #define RT_VARIANT_PWF 16         /* bit 4: one persistent kernel of workgroup-local wavefronts (rt_pwf.hip, the default); a frame that
                                    * does not fit its arenas is rendered by the per-pixel kernel on static tiles */
-#define RT_VARIANT_PWF_ASYNC 32   /* bit 5 (with bit 4): its waves claim queue pages on their own instead of iterating between barriers (rt_pwf_async.hip) */
-#define RT_VARIANT_MAX 63
+#define RT_VARIANT_MAX 31
 #define RT_VARIANT_DEFAULT (RT_VARIANT_PWF | RT_VARIANT_SGPR | RT_VARIANT_STATIC)
 #define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 
@@ -108,13 +107,10 @@ struct PwParams {
     uint32_t tile_stride;   /* the k-th tile handed out is (k * tile_stride) mod n_tiles; coprime to n_tiles */
     const uint32_t *tile_order; /* or, when set, tile_order[k] (n_tiles entries, a permutation) */
 };
-uint32_t pwf_threads();
-int pwf_workgroups_per_cu();
+int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap);
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap);
 hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream, bool async);
-int pwf_async_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap);
-void launch_pwf_async_main(const KernelScene &sc, const PwParams &pp, float *out, uint32_t workgroups, hipStream_t stream);
+                      uint32_t workgroups, hipStream_t stream);
 
 /* distributed pass (rt_distributed.hip) */
 struct DistParams {

@@ -1,6 +1,5 @@
 /*
- * rt_pwf_common.h — item encodings and small helpers shared by the persistent-wavefront kernels (rt_pwf.hip,
- * rt_pwf_async.hip).  Device code only.
+ * rt_pwf_common.h — item encodings and small helpers of the persistent-wavefront kernel (rt_pwf.hip).  Device code only.
  */
 #ifndef RT_PWF_COMMON_H
 #define RT_PWF_COMMON_H

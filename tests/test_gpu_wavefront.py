@@ -13,7 +13,7 @@ import _scenes
 pytestmark = pytest.mark.gpu
 
 PWF = 16
-PATHS = [PWF | 2, 32 | PWF | 2]  # barrier iterations; barrier-free page claiming
+PATHS = [PWF | 2]
 
 
 def _check(world, cam, frame, budget=None, scene=None, variant=PWF | 2):
