@@ -289,6 +289,74 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         /* 1.05 R^2, plus the float rounding of the centre (<= 1e-7 * extent per axis, far inside the margin), rounded up */
         t.bq = std::nextafter((float)(1.05 * r2 * 1.0001), std::numeric_limits<float>::infinity());
     }
+    /* the triangles as runs for the intersection loop; runs of one object's triangles become clusters (rt_device_scene.h) */
+    std::vector<rt::DevSegment> segments;
+    {
+        const bool clusters_off = filter_off || getenv("RT_AMD_NO_CLUSTERS") != nullptr; /* A/B switch; results are the same either way */
+        auto push_plain = [&](uint32_t first, uint32_t count) {
+            if (!segments.empty() && segments.back().n_normals == 0u && segments.back().first + segments.back().count == first) {
+                segments.back().count += count; /* adjacent plain runs are one segment */
+                return;
+            }
+            rt::DevSegment g;
+            memset(&g, 0, sizeof g);
+            g.first = first;
+            g.count = count;
+            segments.push_back(g);
+        };
+        for (uint32_t i = 0; i < desc->n_triangles;) {
+            uint32_t j = i;
+            while (j < desc->n_triangles && desc->triangles[j].object_index == desc->triangles[i].object_index) ++j;
+            bool ok = !clusters_off && j - i >= 8u;
+            for (uint32_t k = i; ok && k < j; ++k) ok = std::isfinite(tris[k].bq); /* every triangle qualifies for its own rejection */
+            rt::DevSegment g;
+            memset(&g, 0, sizeof g);
+            if (ok) {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (uint32_t k = i; k < j; ++k)
+                    for (int v = 0; v < 3; ++v)
+                        for (int a = 0; a < 3; ++a) {
+                            const double x = (double)desc->triangles[k].vertices[v].position[a];
+                            if (x < lo[a]) lo[a] = x;
+                            if (x > hi[a]) hi[a] = x;
+                        }
+                for (int a = 0; a < 3; ++a) g.c[a] = (float)(0.5 * (lo[a] + hi[a]));
+                double r2 = 0.0;
+                for (uint32_t k = i; k < j; ++k) { /* the sphere must contain every triangle's own bounding sphere */
+                    const double dx = (double)tris[k].bcx - g.c[0], dy = (double)tris[k].bcy - g.c[1], dz = (double)tris[k].bcz - g.c[2];
+                    const double reach = sqrt(dx * dx + dy * dy + dz * dz) + sqrt((double)tris[k].bq);
+                    if (reach * reach > r2) r2 = reach * reach;
+                }
+                const double radius = sqrt(r2);
+                ok = std::isfinite(radius) && radius <= max_frac * scene_extent && radius >= 1e-3 * scene_extent;
+                /* one representative per face plane direction: sign canonicalised, merged within 1e-4 per component */
+                for (uint32_t k = i; ok && k < j; ++k) {
+                    float n[3] = {tris[k].n[0], tris[k].n[1], tris[k].n[2]};
+                    ok = std::isfinite(n[0]) && std::isfinite(n[1]) && std::isfinite(n[2]);
+                    const int lead = fabsf(n[0]) > 1e-3f ? 0 : (fabsf(n[1]) > 1e-3f ? 1 : 2);
+                    if (n[lead] < 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                    bool known = false;
+                    for (uint32_t q = 0; q < g.n_normals && !known; ++q)
+                        known = fabsf(g.normals[q][0] - n[0]) <= 1e-4f && fabsf(g.normals[q][1] - n[1]) <= 1e-4f && fabsf(g.normals[q][2] - n[2]) <= 1e-4f;
+                    if (!known && ok) {
+                        if (g.n_normals == RT_SEGMENT_NORMALS) { ok = false; break; }
+                        g.normals[g.n_normals][0] = n[0]; g.normals[g.n_normals][1] = n[1]; g.normals[g.n_normals][2] = n[2];
+                        g.n_normals += 1u;
+                    }
+                }
+                /* (1.05 R)^2 with R already holding the triangles' own 1.05 margins: generous, and rounded up */
+                g.r2_hi = std::nextafter((float)(r2 * 1.0001), std::numeric_limits<float>::infinity());
+            }
+            if (ok && g.n_normals != 0u) {
+                g.first = i;
+                g.count = j - i;
+                segments.push_back(g);
+            } else {
+                push_plain(i, j - i);
+            }
+            i = j;
+        }
+    }
     std::vector<rt::DevSphere> spheres(desc->n_spheres);
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const rt_sphere &s = desc->spheres[i];
@@ -306,7 +374,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     const size_t off_spheres = off_attrs + up(attrs.size() * sizeof(rt::DevTriAttr));
     const size_t off_mats = off_spheres + up(spheres.size() * sizeof(rt::DevSphere));
     const size_t off_lights = off_mats + up(desc->n_materials * sizeof(rt_material));
-    const size_t total = off_lights + up(desc->n_lights * sizeof(rt_light)) + 256;
+    const size_t off_segments = off_lights + up(desc->n_lights * sizeof(rt_light));
+    const size_t total = off_segments + up(segments.size() * sizeof(rt::DevSegment)) + 256;
 
     std::vector<unsigned char> blob(total, 0);
     if (!tris.empty()) memcpy(&blob[off_tris], tris.data(), tris.size() * sizeof(rt::DevTri));
@@ -314,6 +383,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (!spheres.empty()) memcpy(&blob[off_spheres], spheres.data(), spheres.size() * sizeof(rt::DevSphere));
     if (desc->n_materials) memcpy(&blob[off_mats], desc->materials, desc->n_materials * sizeof(rt_material));
     if (desc->n_lights) memcpy(&blob[off_lights], desc->lights, desc->n_lights * sizeof(rt_light));
+    if (!segments.empty()) memcpy(&blob[off_segments], segments.data(), segments.size() * sizeof(rt::DevSegment));
 
     rt_scene *sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -336,6 +406,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.n_spheres = desc->n_spheres;
     sc->ks.n_materials = desc->n_materials;
     sc->ks.n_lights = desc->n_lights;
+    sc->ks.segments = reinterpret_cast<const rt::DevSegment *>(base + off_segments);
+    sc->ks.n_segments = (uint32_t)segments.size();
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);

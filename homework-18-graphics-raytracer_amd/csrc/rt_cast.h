@@ -132,24 +132,41 @@ static __device__ unsigned long long g_stage_totals[8]; /* per translation unit;
 #define RT_STAGE_OPERANDS
 #endif
 
-/* The asm part over the triangle range [index_base, index_base + n): returns the range's nearest accepted hit
- * under the reference's sequential rule, as (best_t, best_prim) with best_prim a GLOBAL triangle index or -1. */
+/* Lane predicates of one cast as wave-wide masks (SGPR pairs), shared by all its segments */
+struct CastMasks {
+    unsigned long long keep_back, keep_front, ex_if_back, ex_if_front, filter_ok;
+};
+__device__ __forceinline__ CastMasks cast_masks(const Ray &ray, float filter_origin2) {
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+    CastMasks m;
+    m.keep_back = __builtin_amdgcn_ballot_w64(ray.mode != FACE_FRONT); /* backfaces survive culling */
+    m.keep_front = __builtin_amdgcn_ballot_w64(ray.mode != FACE_BACK);
+    m.ex_if_back = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_FRONT);  /* Back or Both */
+    m.ex_if_front = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_BACK);  /* Front or Both */
+    /* lanes whose origin is inside the scene's neighbourhood may use the bounding-sphere rejections (rt_device_scene.h) */
+    m.filter_ok = __builtin_amdgcn_ballot_w64(dot(ray.o, ray.o) <= filter_origin2);
+    return m;
+}
+
+/* The nearest accepted triangle hit of a cast so far: best_t = NaN / prim = -1 while None; nd_areas = the winner's n.d
+ * (its sign is the backface flag) and its three signed areas as they stood when it was accepted. */
+struct TriBest {
+    float t;
+    int32_t prim; /* global triangle index */
+    float nd, a0, a1, a2;
+};
+
+/* The asm part over the triangle range [index_base, index_base + n): continues `best` under the reference's sequential
+ * rule (ranges must be visited in index order). */
 __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uint32_t n, uint32_t index_base, const Ray &ray,
-                                                   float filter_origin2, float *out_t, int32_t *out_prim, float *out_nd_areas = nullptr) {
+                                                   const CastMasks &m, TriBest *best) {
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
-    const uint32_t ex_face = (ray.excl >> 29) & 3u;
-    /* lane predicates as wave-wide masks in SGPR pairs */
-    const unsigned long long keep_back = __builtin_amdgcn_ballot_w64(ray.mode != FACE_FRONT);  /* backfaces survive culling */
-    const unsigned long long keep_front = __builtin_amdgcn_ballot_w64(ray.mode != FACE_BACK);
-    const unsigned long long ex_if_back = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_FRONT);  /* Back or Both */
-    const unsigned long long ex_if_front = __builtin_amdgcn_ballot_w64(ex_some && ex_face != FACE_BACK);  /* Front or Both */
-    /* lanes whose origin is inside the scene's neighbourhood may use the bounding-sphere rejection (rt_device_scene.h) */
-    const unsigned long long filter_ok = __builtin_amdgcn_ballot_w64(dot(ray.o, ray.o) <= filter_origin2);
     const uint32_t exid = (ex_some && ex_prim >= index_base && ex_prim - index_base < n) ? ex_prim - index_base : 0xffffffffu;
-    float best_t = rtdm::quiet_nan();
-    int32_t best_prim = -1;
-    float best_nd = 0.0f, best_a0 = 0.0f, best_a1 = 0.0f, best_a2 = 0.0f;
+    float best_t = best->t;
+    int32_t local_prim = -1; /* index within the range of a hit accepted in this call */
+    float best_nd = best->nd, best_a0 = best->a0, best_a1 = best->a1, best_a2 = best->a2;
     float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13;
     /* the range is wave-uniform by construction; say so, so that it is passed in SGPRs */
     const unsigned long long ptr_v = (unsigned long long)(uintptr_t)tris_range;
@@ -160,32 +177,48 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
     uint32_t stage_counts[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #endif
     asm volatile(RT_CAST_ASM_TEXT
-                 : "+v"(best_t), "+v"(best_prim), "+v"(best_nd), "+v"(best_a0), "+v"(best_a1), "+v"(best_a2), "=&v"(r0), "=&v"(r1),
+                 : "+v"(best_t), "+v"(local_prim), "+v"(best_nd), "+v"(best_a0), "+v"(best_a1), "+v"(best_a2), "=&v"(r0), "=&v"(r1),
                    "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9), "=&v"(r10), "=&v"(r11),
                    "=&v"(r12), "=&v"(r13) RT_STAGE_OPERANDS
-                 : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(keep_back),
-                   "s"(keep_front), "s"(ex_if_back), "s"(ex_if_front), "s"(ptr), "s"(n), "s"(filter_ok)
+                 : "v"(ray.o.x), "v"(ray.o.y), "v"(ray.o.z), "v"(ray.d.x), "v"(ray.d.y), "v"(ray.d.z), "v"(exid), "s"(m.keep_back),
+                   "s"(m.keep_front), "s"(m.ex_if_back), "s"(m.ex_if_front), "s"(ptr), "s"(n), "s"(m.filter_ok)
                  : RT_CAST_ASM_CLOBBERS);
 #ifdef RT_DIAG_STAGES
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { /* first active lane: the counts are wave-uniform */
         for (int k = 0; k < 7; ++k) atomicAdd(&g_stage_totals[k], (unsigned long long)stage_counts[k]);
-        atomicAdd(&g_stage_totals[7], 1ull); /* casts (per wave) */
+        atomicAdd(&g_stage_totals[7], 1ull); /* asm calls (per wave) */
     }
 #endif
-    *out_t = best_t;
-    *out_prim = best_prim >= 0 ? best_prim + (int32_t)index_base : -1;
-    if (out_nd_areas != nullptr) {
-        out_nd_areas[0] = best_nd;
-        out_nd_areas[1] = best_a0;
-        out_nd_areas[2] = best_a1;
-        out_nd_areas[3] = best_a2;
-    }
+    best->t = best_t;
+    if (local_prim >= 0) best->prim = local_prim + (int32_t)index_base;
+    best->nd = best_nd;
+    best->a0 = best_a0;
+    best->a1 = best_a1;
+    best->a2 = best_a2;
+}
+
+/* Can every lane skip a clustered segment (rt_device_scene.h "segments")?  Per lane: the ray's line misses the
+ * cluster's bounding sphere by the margin folded into r2_hi, the ray starts inside the scene's neighbourhood, and it is
+ * not (nearly) parallel to any of the cluster's face planes — so each of its triangles would compute a finite t, a
+ * finite plane point outside its own bounding circle, and reject it on a negative signed area.  Comparisons are written
+ * so that NaN anywhere means "cannot skip". */
+__device__ __forceinline__ bool cluster_skippable(const DevSegment &g, const Ray &ray, const CastMasks &m) {
+    const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - ray.o;
+    const V3 cr = cross(disp, ray.d);
+    const bool miss = dot(cr, cr) > g.r2_hi * dot(ray.d, ray.d);
+    if (__builtin_amdgcn_ballot_w64(miss) != (__builtin_amdgcn_ballot_w64(true) & m.filter_ok) ||
+        (__builtin_amdgcn_ballot_w64(true) & ~m.filter_ok) != 0ull)
+        return false; /* some lane may hit the sphere, or starts far outside the scene */
+    bool steep = true;
+    for (uint32_t k = 0; k < g.n_normals; ++k)
+        steep = steep && rtdm::f_abs(dot(v3(g.normals[k][0], g.normals[k][1], g.normals[k][2]), ray.d)) >= 1.0e-3f;
+    return __builtin_amdgcn_ballot_w64(steep) == __builtin_amdgcn_ballot_w64(true);
 }
 
 /* Everything of World::cast after the triangle loop: the winner's backface flag and signed areas, then the
  * sphere loop (main.rs:264-324), starting from the triangles' nearest hit. */
 __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim,
-                                                  const float *nd_areas = nullptr) {
+                                                  const TriBest *kept = nullptr) {
     const uint32_t nt = sc.n_triangles;
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
@@ -196,11 +229,11 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
     best.bf = 0u;
     best.a0 = best.a1 = best.a2 = 0.0f;
     bool have = best_prim >= 0;
-    if (have && nd_areas != nullptr) { /* kept by the loop at the accept: n.d and the three signed areas of the winner */
-        best.bf = nd_areas[0] > 0.0f ? 1u : 0u;
-        best.a0 = nd_areas[1];
-        best.a1 = nd_areas[2];
-        best.a2 = nd_areas[3];
+    if (have && kept != nullptr) { /* kept by the loop at the accept: n.d and the three signed areas of the winner */
+        best.bf = kept->nd > 0.0f ? 1u : 0u;
+        best.a0 = kept->a0;
+        best.a1 = kept->a1;
+        best.a2 = kept->a2;
     } else if (have) { /* the winner's backface flag and signed areas (main.rs:184, 218-222), same operations as in the loop */
         const DevTri &T = sc.tris[best_prim];
         const V3 n = v3(T.n[0], T.n[1], T.n[2]);
@@ -240,11 +273,18 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
 }
 
 __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
-    float best_t;
-    int32_t best_prim;
-    float nd_areas[4];
-    cast_asm_triangles(sc.tris, sc.n_triangles, 0u, ray, sc.filter_origin2, &best_t, &best_prim, nd_areas);
-    return cast_finish(sc, ray, best_t, best_prim, nd_areas);
+    const CastMasks m = cast_masks(ray, sc.filter_origin2);
+    TriBest best;
+    best.t = rtdm::quiet_nan();
+    best.prim = -1;
+    best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
+    /* the triangles in index order, segment by segment; a clustered segment that no lane can hit is not visited */
+    for (uint32_t k = 0; k < sc.n_segments; ++k) {
+        const DevSegment &g = sc.segments[k];
+        if (g.n_normals != 0u && cluster_skippable(g, ray, m)) continue;
+        cast_asm_triangles(sc.tris + g.first, g.count, g.first, ray, m, &best);
+    }
+    return cast_finish(sc, ray, best.t, best.prim, &best);
 }
 
 /* What the state machine keeps of a Hit (main.rs:139-147). */

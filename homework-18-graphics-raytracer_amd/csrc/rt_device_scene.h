@@ -53,6 +53,25 @@ struct alignas(16) DevTriAttr {
 };
 static_assert(sizeof(DevTriAttr) == 64, "DevTriAttr must be 64 bytes");
 
+/* A run of consecutive triangles.  The intersection loop visits the segments in order (so the reference's sequential
+ * nearest-hit rule is kept).  A segment with n_normals != 0 is a CLUSTER — a run of one object's triangles with a
+ * bounding sphere — and is skipped when, for every lane of the wave, the ray's line misses the sphere inflated by 5 %
+ * (folded into r2_hi), the origin is in the scene's neighbourhood, and |n . d| >= 1e-3 for each representative face
+ * normal (one per face, antipodal ones merged): then every triangle in it computes a finite t and a finite plane point
+ * that lies outside the triangle's own bounding circle by the margin of the per-triangle rejection above, i.e. the
+ * reference would reject it on a negative signed area.  rt_scene_create only clusters runs all of whose triangles
+ * qualify for that per-triangle rejection. */
+#define RT_SEGMENT_NORMALS 8
+struct alignas(16) DevSegment {
+    uint32_t first, count;
+    uint32_t n_normals; /* 0: plain run, always visited */
+    float r2_hi;        /* (1.05 R)^2, rounded up */
+    float c[3];
+    float pad;
+    float normals[RT_SEGMENT_NORMALS][4];
+};
+static_assert(sizeof(DevSegment) == 160, "DevSegment layout");
+
 struct alignas(32) DevSphere {
     float c[3]; float radius;
     float r2;   uint32_t obj; float pad[2];

@@ -50,6 +50,8 @@ struct KernelScene {
     const rt_light *lights;
     uint32_t n_triangles, n_spheres, n_materials, n_lights;
     float filter_origin2; /* rays with |origin|^2 above this skip the bounding-sphere rejection (rt_device_scene.h) */
+    const DevSegment *segments; /* the triangles as runs, clusters among them (rt_device_scene.h) */
+    uint32_t n_segments;
 };
 
 /* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),

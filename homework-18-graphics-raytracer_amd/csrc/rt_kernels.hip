@@ -414,8 +414,10 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
                 const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)coop_lds[COOP_MASK_OFFSET + j * 2u + 1u]);
                 const unsigned long long mj = ((unsigned long long)mhi << 32) | mlo;
                 if (mj == 0ull) continue;
-                float bt = rtdm::quiet_nan();
-                int32_t bp = -1;
+                TriBest part;
+                part.t = rtdm::quiet_nan();
+                part.prim = -1;
+                part.nd = part.a0 = part.a1 = part.a2 = 0.0f;
                 if ((mj >> lane) & 1ull) {
                     const uint32_t *rj = coop_lds + COOP_RAYS_OFFSET + (j * 8u) * 64u + lane;
                     Ray r;
@@ -423,8 +425,10 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
                     r.d = v3(__uint_as_float(rj[3 * 64]), __uint_as_float(rj[4 * 64]), __uint_as_float(rj[5 * 64]));
                     r.mode = rj[6 * 64];
                     r.excl = rj[7 * 64];
-                    cast_asm_triangles(sc.tris + t_base, t_cnt, t_base, r, sc.filter_origin2, &bt, &bp);
+                    cast_asm_triangles(sc.tris + t_base, t_cnt, t_base, r, cast_masks(r, sc.filter_origin2), &part);
                 }
+                const float bt = part.t;
+                const int32_t bp = part.prim;
                 uint32_t *res = coop_lds + COOP_RES_OFFSET + ((j * COOP_WAVES + wslot) * 2u) * 64u + lane;
                 res[0] = __float_as_uint(bt);
                 res[64] = (uint32_t)bp;
@@ -443,7 +447,15 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
                         if (!(best_prim >= 0 && best_t < t)) { best_t = t; best_prim = pr; }
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(saw_nan) != 0ull) cast_asm_triangles(sc.tris, nt, 0u, req, sc.filter_origin2, &best_t, &best_prim);
+                if (__builtin_amdgcn_ballot_w64(saw_nan) != 0ull) {
+                    TriBest whole;
+                    whole.t = rtdm::quiet_nan();
+                    whole.prim = -1;
+                    whole.nd = whole.a0 = whole.a1 = whole.a2 = 0.0f;
+                    cast_asm_triangles(sc.tris, nt, 0u, req, cast_masks(req, sc.filter_origin2), &whole);
+                    best_t = whole.t;
+                    best_prim = whole.prim;
+                }
                 cr = cast_finish(sc, req, best_t, best_prim);
             }
         }

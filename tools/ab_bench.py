@@ -43,7 +43,7 @@ for tag in args.tags.split(","):
     name, var = parts[0], (parts[1] if len(parts) > 1 else "")
     evict = (int(parts[2]), int(parts[3])) if len(parts) > 3 else None
     env = dict(kv.split("=", 1) for kv in parts[2].split(";")) if len(parts) == 3 else {}
-    for k in ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC"):
+    for k in ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC", "RT_AMD_NO_CLUSTERS"):
         os.environ.pop(k, None)
     os.environ.update(env)  # read by rt_scene_create
     path = _capi.PKG_DIR / ("librt_amd.so" if name == "main" else f"variants/librt_amd_{name}.so")
