@@ -736,3 +736,7 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
 }
 
 } /* namespace rt */
+
+#ifdef RT_DIAG_STAGES
+RT_DIAG_STAGE_READER(rt_diag_read_stages_pwf)
+#endif

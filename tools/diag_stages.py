@@ -21,7 +21,8 @@ frame = rt.Frame.full(W, H, depth)
 h = C.c_void_p(); assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0
 out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 names = ["cull", "divide", "p+sphere", "area0", "area1", "area2", "accept"]
-for variant, reader in ((2, lib.rt_diag_read_stages_kernels), (18, lib.rt_diag_read_stages_wavefront)):
+lib.rt_diag_read_stages_pwf.argtypes = lib.rt_diag_read_stages_kernels.argtypes
+for variant, reader in ((2, lib.rt_diag_read_stages_kernels), (18, lib.rt_diag_read_stages_pwf)):
     lib.rt_set_variant(variant)
     buf = (C.c_ulonglong * 8)()
     reader(buf, 1)
@@ -29,6 +30,6 @@ for variant, reader in ((2, lib.rt_diag_read_stages_kernels), (18, lib.rt_diag_r
     torch.cuda.synchronize()
     reader(buf, 1)
     casts = buf[7]
-    print(f"variant {variant}: {casts} wave-casts")
+    print(f"variant {variant}: {casts} calls of the triangle loop (one per visited segment per call)")
     for k, n in enumerate(names):
-        print(f"   {n:9s} {buf[k] / casts:7.2f} per wave-cast")
+        print(f"   {n:9s} {buf[k] / casts:7.2f} per call")
