@@ -608,15 +608,21 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     const uint32_t n_nodes = S.n.alloc < pp.node_cap ? S.n.alloc : pp.node_cap; /* the queued nodes; roots sit at the top */
     const uint32_t max_depth = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0);
     if (!aborted) {
-        /* levels 1 .. max_depth-1 (children before parents; level max_depth are the roots, folded by tile below): a thread
-         * reads 16 nodes' levels at a time and folds the ones that are due */
+        /* levels 1 .. max_depth-1 (children before parents; level max_depth are the roots, folded by tile below).  Thread t
+         * looks after the nodes t, t + 512, t + 1024, ...: neighbouring ids are siblings and cousins of one level, so this
+         * spreads a level's nodes evenly over the threads; their level bytes are fetched sixteen at a time */
         for (uint32_t left = 1u; left < max_depth; ++left) {
-            for (uint32_t base = threadIdx.x * 16u; base < n_nodes; base += PA_THREADS * 16u) {
-                const uint4 lv = *reinterpret_cast<const uint4 *>(fold_level + base);
-                const uint32_t words[4] = {lv.x, lv.y, lv.z, lv.w};
+            for (uint32_t first = threadIdx.x; first < n_nodes; first += PA_THREADS * 16u) {
+                uint32_t lv[16];
+#pragma unroll
                 for (uint32_t k = 0; k < 16u; ++k) {
-                    const uint32_t id = base + k;
-                    if (((words[k >> 2] >> ((k & 3u) * 8u)) & 0xffu) != left || id >= n_nodes) continue;
+                    const uint32_t id = first + k * PA_THREADS;
+                    lv[k] = id < n_nodes ? (uint32_t)fold_level[id] : 0u;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; ++k) {
+                    if (lv[k] != left) continue;
+                    const uint32_t id = first + k * PA_THREADS;
                     const uint4 a = nodes[(size_t)id * 2u], b = nodes[(size_t)id * 2u + 1u];
                     const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
                     V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
@@ -637,35 +643,60 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
             __syncthreads();
         }
+        /* the roots, by tile: a wave takes four tiles at a time so that their dependent loads (record, then children)
+         * overlap */
         const uint32_t n_started = S.tile_list_count;
-        for (uint32_t e = threadIdx.x >> 6; e < n_started; e += PA_WAVES) {
-            const uint32_t tile = tile_list[e * 2u], base = tile_list[e * 2u + 1u];
-            const uint32_t first_slot = tile * 64u;
-            const uint32_t nv = total_slots - first_slot < 64u ? total_slots - first_slot : 64u;
-            if (lane >= nv) continue;
-            const uint32_t id = base + lane;
-            const uint4 a = nodes[(size_t)id * 2u], b = nodes[(size_t)id * 2u + 1u];
-            V3 value = v3(puf(a.x), puf(a.y), puf(a.z));
-            if (b.z != PW_FINAL) {
-                const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
-                V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
-                if (b.z != PW_NO_CHILD) {
-                    const uint4 c = nodes[(size_t)b.z * 2u];
-                    reflection = v3(puf(c.x), puf(c.y), puf(c.z));
+        for (uint32_t e0 = threadIdx.x >> 6; e0 < n_started; e0 += PA_WAVES * 4u) {
+            uint32_t id[4], slot[4];
+            uint4 ra[4], rb[4];
+            bool live[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t e = e0 + j * PA_WAVES;
+                live[j] = false;
+                id[j] = slot[j] = 0u;
+                if (e < n_started) {
+                    const uint32_t tile = tile_list[e * 2u], base = tile_list[e * 2u + 1u];
+                    const uint32_t first_slot = tile * 64u;
+                    const uint32_t nv = total_slots - first_slot < 64u ? total_slots - first_slot : 64u;
+                    live[j] = lane < nv;
+                    id[j] = base + lane;
+                    slot[j] = first_slot + lane;
                 }
-                if (b.w != PW_NO_CHILD) {
-                    const uint4 c = nodes[(size_t)b.w * 2u];
-                    refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay;
+                if (live[j]) {
+                    ra[j] = nodes[(size_t)id[j] * 2u];
+                    rb[j] = nodes[(size_t)id[j] * 2u + 1u];
                 }
-                value = (value + reflection * rc) + refraction * fc;
             }
-            uint32_t row, col;
-            pw_slot_to_pixel(fr, first_slot + lane, &row, &col);
-            /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
-            float *px = out + ((size_t)row * fr.cols + col) * 3u;
-            px[0] = 0.0f + value.x;
-            px[1] = 0.0f + value.y;
-            px[2] = 0.0f + value.z;
+            uint4 cr4[4], cf4[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                cr4[j] = cf4[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (live[j] && rb[j].z != PW_FINAL) {
+                    if (rb[j].z != PW_NO_CHILD) cr4[j] = nodes[(size_t)rb[j].z * 2u];
+                    if (rb[j].w != PW_NO_CHILD) cf4[j] = nodes[(size_t)rb[j].w * 2u];
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (!live[j]) continue;
+                const uint4 a = ra[j], b = rb[j];
+                V3 value = v3(puf(a.x), puf(a.y), puf(a.z));
+                if (b.z != PW_FINAL) {
+                    const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
+                    V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
+                    if (b.z != PW_NO_CHILD) reflection = v3(puf(cr4[j].x), puf(cr4[j].y), puf(cr4[j].z));
+                    if (b.w != PW_NO_CHILD) refraction = v3(puf(cf4[j].x), puf(cf4[j].y), puf(cf4[j].z)) * decay; /* main.rs:508 */
+                    value = (value + reflection * rc) + refraction * fc;
+                }
+                uint32_t row, col;
+                pw_slot_to_pixel(fr, slot[j], &row, &col);
+                /* img[at] = img[at] + photon on a zeroed image (main.rs:1107) */
+                float *px = out + ((size_t)row * fr.cols + col) * 3u;
+                px[0] = 0.0f + value.x;
+                px[1] = 0.0f + value.y;
+                px[2] = 0.0f + value.z;
+            }
         }
         if (threadIdx.x == 0u && n_started != 0u) atomicAdd(pp.global + PW_G_TILES_DONE, n_started);
     }
