@@ -63,7 +63,9 @@
 
 namespace rt {
 
+#ifndef PA_WAVES
 #define PA_WAVES 8u
+#endif
 #define PA_THREADS (PA_WAVES * 64u)
 #ifndef PA_MIN_WAVES
 #define PA_MIN_WAVES 6
