@@ -482,7 +482,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     }
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);
-    uint32_t pw_groups = 0;
+    uint32_t pw_groups = 0, pw_band_rows = 0;
     if (g_evict_threshold < 0) {
         const char *v = getenv("RT_AMD_EVICT_THRESHOLD");
         g_evict_threshold = (v && *v) ? atoi(v) : 16;
@@ -526,29 +526,33 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             qs.tile_order = ws.d_tiles;
         }
         if (variant & RT_VARIANT_PWF) {
+            /* The kernel keeps one LDS word per 64 ring slots and per 64 nodes, so an arena holds 64 K ring slots at most.
+             * A tile too large for that at the budget asked for (beyond ~8 Mpixel at 6 nodes per pixel) is rendered as
+             * several bands of rows, one launch each, through the same workspace. */
+            const uint64_t ring_max = 1ull << 16;
             const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
-            const uint64_t tiles = (pixels + 63u) / 64u;
-            uint64_t groups = tiles; /* a workgroup fetches one to eight tiles at a time */
+            uint64_t groups = (pixels + 63u) / 64u; /* a workgroup fetches one to eight tiles at a time */
             if (groups > scene->pwf_workgroups) groups = scene->pwf_workgroups;
             if (groups < 1) groups = 1;
-            const uint64_t want = (pixels * (uint64_t)g_wf_nodes_per_pixel + groups - 1) / groups; /* nodes per arena */
+            const uint64_t max_pixels = (ring_max - 1024u) * groups / (uint64_t)g_wf_nodes_per_pixel;
+            pw_band_rows = kf.rows;
+            if (pixels > max_pixels) {
+                const uint64_t n_bands = (pixels + max_pixels - 1) / max_pixels;
+                uint64_t rows = (kf.rows + n_bands - 1) / n_bands;
+                rows = (rows + 7u) & ~7ull; /* whole 8-row tile bands */
+                pw_band_rows = (uint32_t)(rows < kf.rows ? rows : kf.rows);
+            }
+            const uint64_t band_pixels = (uint64_t)kf.cols * pw_band_rows;
+            const uint64_t want = (band_pixels * (uint64_t)g_wf_nodes_per_pixel + groups - 1) / groups; /* nodes per arena */
             /* tiles are handed out dynamically, so a workgroup may end up with several times the average: arenas have a
              * floor of 8192 ring slots (1.5 MB) however small the frame (budgets below 4 waive it: tests of the fallback) */
             uint64_t ring = g_wf_nodes_per_pixel >= 4 ? 8192 : 2048;
-            /* (the kernel keeps one LDS word per 64 ring slots and 64 nodes: 64 K slots at most) */
-            while (ring < want + 1024u && ring < (1ull << 16)) ring <<= 1;
+            while (ring < want + 1024u && ring < ring_max) ring <<= 1;
             pw.ring_cap = (uint32_t)ring;
-            pw.node_cap = (uint32_t)(ring - 1024u);
             /* (the budget sizes the rings; an arena may use all of its ring's worth of nodes: tiles are handed out
              * dynamically, and a workgroup that met expensive ones needs more than the average) */
+            pw.node_cap = (uint32_t)(ring - 1024u);
             pw.tile_reserve = 10;
-            {   /* a stride near the golden section of the tile count scatters consecutive fetches over the image */
-                auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
-                uint64_t stride = (uint64_t)((double)tiles * 0.6180339887498949);
-                if (stride < 1) stride = 1;
-                while (gcd(stride, tiles) != 1) stride += 1;
-                pw.tile_stride = (uint32_t)stride;
-            }
             pw.arena_stride = (rt::pwf_arena_bytes(pw.node_cap, pw.ring_cap) + 255u) & ~(size_t)255u;
             const size_t need = 256 + (size_t)groups * pw.arena_stride;
             if (need > ws.pwf_bytes) {
@@ -584,11 +588,31 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     }
     hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
     if (e == hipSuccess && (variant & RT_VARIANT_PWF)) {
-        e = rt::launch_pwf(scene->ks, kf, d_rgb, d_ray_count, pw, pw_groups, stream);
-        /* a frame that did not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
+        /* a band that does not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
         qs.run_if = pw.global + PW_G_OVERFLOW;
-        variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC;
-        rt::set_main_kernel_events(nullptr, nullptr); /* the pair brackets the persistent kernel, not the fallback */
+        for (uint32_t r0 = 0; e == hipSuccess && r0 < kf.rows; r0 += pw_band_rows) {
+            rt::KernelFrame band = kf;
+            band.y0 = kf.y0 + r0 * kf.y_step;
+            band.rows = kf.rows - r0 < pw_band_rows ? kf.rows - r0 : pw_band_rows;
+            float *band_rgb = d_rgb + (size_t)r0 * kf.cols * 3u;
+            {   /* a stride near the golden section of the tile count scatters consecutive tile fetches over the image */
+                auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+                const uint64_t tiles = ((uint64_t)band.cols * band.rows + 63u) / 64u;
+                uint64_t stride = (uint64_t)((double)tiles * 0.6180339887498949);
+                if (stride < 1) stride = 1;
+                while (gcd(stride, tiles) != 1) stride += 1;
+                pw.tile_stride = (uint32_t)stride;
+            }
+            const bool first = r0 == 0, last = r0 + pw_band_rows >= kf.rows;
+            e = rt::launch_pwf(scene->ks, band, band_rgb, d_ray_count, pw, pw_groups, stream, first, last);
+            if (e == hipSuccess) {
+                rt::mute_main_kernel_events(true); /* the event pair brackets the persistent kernel(s), not the fallback */
+                e = rt::launch_whitted(scene->ks, band, band_rgb, d_ray_count, qs, scene->resident_waves, stream, RT_VARIANT_SGPR | RT_VARIANT_STATIC);
+                rt::mute_main_kernel_events(false);
+            }
+        }
+        if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
+        return RT_OK;
     }
     if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);

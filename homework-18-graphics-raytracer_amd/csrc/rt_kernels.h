@@ -88,6 +88,7 @@ struct KernelQueues {
 uint32_t cont_record_dwords(int32_t max_depth);
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hook, see rt_profile_* */
 void record_main_kernel_event(int which, hipStream_t stream);    /* 0: start, 1: stop; no-op when profiling is off */
+void mute_main_kernel_events(bool muted);                        /* launches in between are not the render kernel */
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                           const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
@@ -112,7 +113,7 @@ struct PwParams {
 int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap);
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap);
 hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream);
+                      uint32_t workgroups, hipStream_t stream, bool first_band, bool last_band);
 
 /* distributed pass (rt_distributed.hip) */
 struct DistParams {

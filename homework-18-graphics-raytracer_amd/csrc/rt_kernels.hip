@@ -759,18 +759,20 @@ static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, floa
 
 /* optional HIP events recorded on the launch stream right around the dominant (render) kernel of a call */
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static bool g_ev_muted = false; /* set around launches that are not "the" render kernel (the wavefront path's fallback) */
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+void mute_main_kernel_events(bool muted) { g_ev_muted = muted; }
 void record_main_kernel_event(int which, hipStream_t stream) {
     hipEvent_t ev = which == 0 ? g_ev_start : g_ev_stop;
-    if (ev) (void)hipEventRecord(ev, stream);
+    if (ev && !g_ev_muted) (void)hipEventRecord(ev, stream);
 }
 
 template <int MAXD, int MODE>
 static hipError_t launch_main(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
                               const KernelQueues &qs, uint32_t waves, hipStream_t stream, bool use_lds) {
-    if (g_ev_start) (void)hipEventRecord(g_ev_start, stream);
+    record_main_kernel_event(0, stream);
     const hipError_t e = launch_mode<MAXD, MODE>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
-    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, stream);
+    record_main_kernel_event(1, stream);
     return e;
 }
 
@@ -801,9 +803,9 @@ static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out,
     if ((variant & RT_VARIANT_COOP) != 0 && !use_lds) {
         const uint32_t groups = (fr.n_chunks + COOP_WAVES - 1u) / COOP_WAVES;
         if (groups == 0u) return hipSuccess;
-        if (g_ev_start) (void)hipEventRecord(g_ev_start, stream);
+        record_main_kernel_event(0, stream);
         hipLaunchKernelGGL((whitted_coop_kernel<MAXD>), dim3(groups), dim3(COOP_WAVES * 64), COOP_LDS_BYTES, stream, sc, fr, out, ray_count, qs);
-        if (g_ev_stop) (void)hipEventRecord(g_ev_stop, stream);
+        record_main_kernel_event(1, stream);
         return hipGetLastError();
     }
     if (scheme == RT_VARIANT_PERSISTENT) {

@@ -752,7 +752,7 @@ extern "C" int rt_diag_read_pwf(uint32_t *out32) {
 #endif
 
 hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream) {
+                      uint32_t workgroups, hipStream_t stream, bool first_band, bool last_band) {
     const uint32_t total = fr.cols * fr.rows;
     fr.n_chunks = (total + 63u) / 64u;
     if (total == 0u) return hipSuccess;
@@ -760,10 +760,10 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
     g_pw_last_global = pp.global;
 #endif
     hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
-    record_main_kernel_event(0, stream);
+    if (first_band) record_main_kernel_event(0, stream); /* the pair brackets all bands of a call (one, up to ~8 Mpixel) */
     const size_t lds = (size_t)((pp.node_cap + 63u) / 64u + 2u * (pp.ring_cap / 64u)) * sizeof(uint32_t);
     hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
-    record_main_kernel_event(1, stream);
+    if (last_band) record_main_kernel_event(1, stream);
     hipLaunchKernelGGL(pwf_finish_kernel, dim3(1), dim3(1), 0, stream, pp.global, fr.n_chunks, ray_count);
     return hipGetLastError();
 }

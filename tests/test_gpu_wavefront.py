@@ -97,3 +97,20 @@ def test_wavefront_row_tiles_equal_the_full_frame(ref, variant):
             assert (band.view(np.uint32) == full[rank::3].view(np.uint32)).all()
     finally:
         _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
+
+
+@pytest.mark.parametrize("w,h,depth", [(256, 256, 5), (250, 203, 3)])
+def test_oversized_tiles_are_rendered_as_row_bands(ref, w, h, depth):
+    """An arena holds 64 K ring slots at most; a tile whose budget needs more is split into bands of rows, one launch
+    each.  A huge budget forces that on a small frame (two or three bands, the last one ragged)."""
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(w, h, depth), budget=1024, scene=scene)
+    # ... also for an interleaved (multi-GPU) share of the frame
+    lib = _capi.amd_lib()
+    full, _ = _oracle.render_whitted(world.desc(), cam, rt.Frame.full(w, h, depth))
+    _capi.check(lib.rt_set_wavefront_budget(2048))
+    try:
+        band, _ = rt.render_whitted_numpy(scene, cam, rt.Frame.rows_of_rank(w, h, depth, 1, 2))
+    finally:
+        _capi.check(lib.rt_set_wavefront_budget(6))
+    assert (band.view(np.uint32) == full[1::2].view(np.uint32)).all()
