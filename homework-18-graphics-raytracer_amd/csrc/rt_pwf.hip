@@ -197,6 +197,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     uint32_t casts = 0u;
 #ifdef PA_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t st_hist[5] = {0u, 0u, 0u, 0u, 0u}; /* chunks by item count: <= 8, <= 16, <= 32, < 64, 64 */
 #endif
 
     for (;;) {
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
         if (type == PA_T_NONE) continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the page's items were written before they were counted */
+#ifdef PA_STATS
+        st_hist[count <= 8u ? 0 : (count <= 16u ? 1 : (count <= 32u ? 2 : (count < 64u ? 3 : 4)))] += 1u;
+#endif
 
         /* ---- load the chunk's items and set up their rays ---- */
         const bool active = lane < count;
@@ -707,6 +711,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     {
         const unsigned long long st_t3 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0u) { atomicAdd(pp.global + 8, (uint32_t)(st_t1 - st_t0)); atomicMax(pp.global + 9, (uint32_t)(st_t1 - st_t0)); } /* per wave: own loop */
+        if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(pp.global + 20 + k, st_hist[k]);
         if (threadIdx.x == 0u) {
             atomicAdd(pp.global + 10, (uint32_t)(st_t2 - st_t0)); atomicMax(pp.global + 11, (uint32_t)(st_t2 - st_t0)); /* until the last wave left the loop */
             atomicAdd(pp.global + 12, (uint32_t)(st_t3 - st_t2)); atomicMax(pp.global + 13, (uint32_t)(st_t3 - st_t2)); /* fold */

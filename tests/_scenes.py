@@ -82,3 +82,68 @@ def camera(seed=0):
     cam.up = (0.0, 1.0, 0.0)
     cam.near = float(rng.choice([-0.1, 0.0, 0.2]))
     return cam
+
+
+def _box(center, half, rot):
+    """The 12 triangles of a box (outward winding): corners c + rot @ (+-hx, +-hy, +-hz)."""
+    c = np.asarray(center, dtype=np.float64)
+    h = np.asarray(half, dtype=np.float64)
+    corner = lambda sx, sy, sz: (c + rot @ (h * np.array([sx, sy, sz]))).tolist()
+    quads = [  # each face as a quad in counter-clockwise order seen from outside
+        [(1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1)], [(-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, -1, -1)],
+        [(-1, 1, -1), (-1, 1, 1), (1, 1, 1), (1, 1, -1)], [(-1, -1, 1), (-1, -1, -1), (1, -1, -1), (1, -1, 1)],
+        [(-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)], [(1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, -1)],
+    ]
+    tris = []
+    for q in quads:
+        p = [corner(*v) for v in q]
+        tris.append([p[0], p[1], p[2]])
+        tris.append([p[0], p[2], p[3]])
+    return tris
+
+
+def _rotation(rng):
+    q = rng.normal(0, 1, 4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def clustered_world(seed, n_boxes=4, axis_aligned=False, n_spheres=2):
+    """Objects whose triangles are consecutive (so that rt_scene_create clusters them: csrc/rt_device_scene.h "segments"):
+    a floor, then boxes of 12 triangles each — randomly rotated, or axis-aligned with round coordinates so that rays
+    parallel to faces and origins on face planes occur exactly."""
+    rng = np.random.default_rng(seed)
+    w = rt.World()
+    floor = w.push_object(material(rng, "plain"))
+    floor.push_square([(-4, -0.5, -4), (-4, -0.5, 4), (4, -0.5, 4), (4, -0.5, -4)], [(0, 0), (0, 1), (1, 0), (0, 1)])
+    for b in range(n_boxes):
+        obj = w.push_object(material(rng, "plain"))
+        if axis_aligned:
+            centre = np.array([float(rng.integers(-3, 4)) * 0.5, float(rng.integers(0, 3)) * 0.5, float(rng.integers(-3, 4)) * 0.5])
+            half = np.array([0.25, 0.5, 0.25]) * float(rng.integers(1, 3))
+            rot = np.eye(3)
+        else:
+            centre = rng.uniform(-1.5, 1.5, 3) + np.array([0, 0.6, 0])
+            half = rng.uniform(0.15, 0.5, 3)
+            rot = _rotation(rng)
+        for tri in _box(centre, half, rot):
+            obj.push_flat_triangle(tri, rng.uniform(0, 1, (3, 2)).tolist())
+    for _ in range(n_spheres):
+        w.push_object(material(rng, "plain")).push_sphere(tuple(rng.uniform(-1.5, 1.5, 3) + np.array([0, 0.6, 0])), float(rng.uniform(0.2, 0.5)))
+    for i in range(3):
+        w.push_light(light(rng, i % 3))
+    return w
+
+
+def axis_camera(eye, toward=(0.0, 0.0, -1.0)):
+    """A camera whose centre column / row rays have exact zeros in their directions."""
+    cam = Camera()
+    cam.fovy = float(np.float32(np.radians(60.0)))
+    cam.center = tuple(float(x) for x in eye)
+    cam.toward = tuple(float(x) for x in toward)
+    cam.up = (0.0, 1.0, 0.0)
+    cam.near = 0.0
+    return cam

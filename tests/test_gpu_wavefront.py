@@ -114,3 +114,22 @@ def test_oversized_tiles_are_rendered_as_row_bands(ref, w, h, depth):
     finally:
         _capi.check(lib.rt_set_wavefront_budget(6))
     assert (band.view(np.uint32) == full[1::2].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("variant", [PWF | 2, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_clustered_objects_random(seed, variant):
+    """Scenes whose objects become cluster segments (12-triangle boxes): whole-object skipping must not change a bit."""
+    world = _scenes.clustered_world(seed, n_boxes=3 + seed % 3)
+    _check(world, _scenes.camera(seed), rt.Frame.full(96, 64, 6), budget=16, variant=variant)
+
+
+@pytest.mark.parametrize("variant", [PWF | 2, 2])
+@pytest.mark.parametrize("seed,eye", [(11, (0.0, 0.5, 3.0)), (12, (0.5, 0.5, 3.0)), (13, (0.25, 1.0, 2.5)), (14, (0.0, -0.5, 3.0)), (15, (1.0, 0.0, 3.0))])
+def test_clustered_objects_degenerate_rays(seed, eye, variant):
+    """Axis-aligned boxes on a half-unit grid seen by an axis-aligned camera from a grid point: rays parallel to faces
+    (n.d == 0: t = +-inf or NaN, NaN areas, which the reference ACCEPTS) and origins on face planes.  A cluster may only
+    be skipped when no lane can produce such a hit."""
+    world = _scenes.clustered_world(seed, n_boxes=5, axis_aligned=True)
+    for w, h in ((64, 64), (65, 33)):  # even sizes put clip_x == 0 / clip_y == 0 on pixel centres
+        _check(world, _scenes.axis_camera(eye), rt.Frame.full(w, h, 5), budget=16, variant=variant)

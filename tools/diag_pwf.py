@@ -32,3 +32,5 @@ print(f"workgroups {wgs}; nodes/WG {g[15] / wgs:.0f}")
 print(f"wave's own loop: mean {g[8] / (8 * wgs) / 100:.1f} us, max {g[9] / 100:.1f} us")
 print(f"until the WG's last wave left the loop: mean {g[10] / wgs / 100:.1f} us, max {g[11] / 100:.1f} us")
 print(f"fold: mean {g[12] / wgs / 100:.1f} us, max {g[13] / 100:.1f} us;  whole WG: min {g[16] / 100:.1f} us, max {g[17] / 100:.1f} us")
+h = [g[20 + k] for k in range(5)]
+print("chunks by item count (<=8, <=16, <=32, <64, 64):", h, "shares", [round(x / max(1, sum(h)), 3) for x in h])
