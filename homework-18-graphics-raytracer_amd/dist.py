@@ -83,3 +83,72 @@ def accumulate_epochs_sharded(render_epochs: Callable[[Frame], "object"], width:
     """
     frame = shard_frame(width, height, max_depth, rank, world)
     return gather_frame(render_epochs(frame), height, rank, world, dst=dst, group=group, staging=staging)
+
+
+class FramePipeline:
+    """A sequence of frames with the gather of frame k overlapped with the rendering of frame k+1.
+
+    A rank's share of a 1080p frame renders in ~0.5 ms; the gather to rank 0 (RCCL over xGMI, which runs on its own
+    stream) and the de-interleave cost a comparable time, so doing them back to back halves the frame rate.  Here a
+    rank renders into one of two band buffers; the gather of that band is started asynchronously, and only before
+    the buffer is written again (two frames later) — or when the frame is collected on rank 0 — does the compute stream
+    wait for it.  Nothing is allocated per frame.
+
+        pipe = FramePipeline(width, height, max_depth, rank, world)
+        for k in range(n):
+            band = pipe.band(k)                 # (rows, width, 3) view to render frame k's share into
+            render(pipe.frame, band)            # stream-ordered on the current stream
+            full = pipe.submit(k)               # starts frame k's gather; returns frame k-1 assembled (rank 0), or None
+        last = pipe.finish()                    # frame n-1 assembled (rank 0)
+    """
+
+    def __init__(self, width: int, height: int, max_depth: int, rank: int, world: int, dst: int = 0, group=None, device="cuda"):
+        import torch
+
+        self.frame = shard_frame(width, height, max_depth, rank, world)
+        self.height, self.rank, self.world, self.dst, self.group = height, rank, world, dst, group
+        self.max_rows = band_rows(height, 0, world)
+        # padded to the common band size so that ragged last bands need no per-frame copy
+        self._bands = [torch.zeros((self.max_rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)]
+        self._staging = [torch.empty((world, self.max_rows, width, 3), dtype=torch.float32, device=device) for _ in range(2)] if rank == dst else None
+        self._work = [None, None]
+        self._last = -1
+
+    def band(self, k: int):
+        slot = k % 2
+        if self._work[slot] is not None:  # the gather that read this buffer two frames ago
+            self._work[slot].wait()
+            self._work[slot] = None
+        return self._bands[slot][: self.frame.rows]
+
+    def _assemble(self, k: int):
+        slot = k % 2
+        if self._work[slot] is not None:
+            self._work[slot].wait()
+            self._work[slot] = None
+        if self.rank != self.dst:
+            return None
+        st = self._staging[slot]
+        full = st.permute(1, 0, 2, 3).reshape(self.max_rows * self.world, st.shape[2], 3)  # image row y = k*world + r
+        return full[: self.height].contiguous() if self.max_rows * self.world != self.height else full.contiguous()
+
+    def submit(self, k: int):
+        import torch.distributed as dist
+
+        slot = k % 2
+        if self.rank == self.dst:
+            self._work[slot] = dist.gather(self._bands[slot], [self._staging[slot][r] for r in range(self.world)], dst=self.dst,
+                                           group=self.group, async_op=True)
+        else:
+            self._work[slot] = dist.gather(self._bands[slot], None, dst=self.dst, group=self.group, async_op=True)
+        prev = self._assemble(k - 1) if k >= 1 else None
+        self._last = k
+        return prev
+
+    def finish(self):
+        out = self._assemble(self._last) if self._last >= 0 else None
+        for slot in range(2):
+            if self._work[slot] is not None:
+                self._work[slot].wait()
+                self._work[slot] = None
+        return out

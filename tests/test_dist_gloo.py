@@ -65,6 +65,57 @@ def test_sharded_frame_equals_single_process(tmp_path, world, w, h):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def _pipeline_worker(rank, world, port, w, h, depths, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+    import _oracle
+
+    wd = rt.reference_world()
+    cam = rt.reference_camera()
+    # frames differ (one depth each) so that a mixed-up buffer would show
+    pipe = rtdist.FramePipeline(w, h, max(depths), rank, world, device="cpu")
+    frames = []
+    for k, depth in enumerate(depths):
+        band = pipe.band(k)
+        fr = rtdist.shard_frame(w, h, depth, rank, world)
+        img, _ = _oracle.render_whitted(wd.desc(), cam, fr, threads=2)
+        band.copy_(torch.from_numpy(img))
+        prev = pipe.submit(k)
+        if k >= 1 and rank == 0:
+            frames.append(prev.numpy().copy())
+        else:
+            assert k == 0 or prev is None or rank == 0
+    last = pipe.finish()
+    if rank == 0:
+        frames.append(last.numpy().copy())
+        np.save(out_path, np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 48, 36), (3, 40, 31)])
+def test_pipelined_gather_delivers_every_frame_in_order(tmp_path, world, w, h):
+    """dist.FramePipeline (what bench.py uses for N > 1): the gather of frame k overlaps the rendering of frame k+1;
+    rank 0 must still get every frame, complete and in order, through its two alternating buffers."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import homework_18_graphics_raytracer_amd as rt
+    import _oracle
+
+    depths = [0, 1, 2, 3, 1]
+    out = tmp_path / "frames.npy"
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), w, h, depths, str(out)), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape[0] == len(depths)
+    for k, depth in enumerate(depths):
+        want, _ = _oracle.render_whitted(rt.reference_world().desc(), rt.reference_camera(), rt.Frame.full(w, h, depth))
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"frame {k}"
+
+
 def _dist_worker(rank, world, port, w, h, depth, epochs, out_path):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
