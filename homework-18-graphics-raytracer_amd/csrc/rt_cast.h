@@ -278,12 +278,20 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
     best.t = rtdm::quiet_nan();
     best.prim = -1;
     best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
-    /* the triangles in index order, segment by segment; a clustered segment that no lane can hit is not visited */
+    /* The triangles in index order, segment by segment; a clustered segment that no lane can hit is not visited.
+     * Neighbouring segments that are visited go through the loop in one call (its set-up and first fetches are paid once). */
+    uint32_t run_first = 0u, run_count = 0u;
     for (uint32_t k = 0; k < sc.n_segments; ++k) {
         const DevSegment &g = sc.segments[k];
-        if (g.n_normals != 0u && cluster_skippable(g, ray, m)) continue;
-        cast_asm_triangles(sc.tris + g.first, g.count, g.first, ray, m, &best);
+        if (g.n_normals != 0u && cluster_skippable(g, ray, m)) {
+            if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
+            run_count = 0u;
+            continue;
+        }
+        if (run_count == 0u) run_first = g.first;
+        run_count += g.count; /* segments are contiguous in triangle order */
     }
+    if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
     return cast_finish(sc, ray, best.t, best.prim, &best);
 }
 
