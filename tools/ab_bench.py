@@ -33,6 +33,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--world", type=int, default=1, help="render only rank 0's interleaved row band of this many ranks (a multi-GPU share)")
 args = ap.parse_args()
 
+ENV_KNOBS = ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC", "RT_AMD_NO_CLUSTERS", "RT_AMD_PWF_RING")
 world = rt.reference_world()
 cam = rt.reference_camera()
 desc = world.desc()
@@ -43,9 +44,9 @@ for tag in args.tags.split(","):
     name, var = parts[0], (parts[1] if len(parts) > 1 else "")
     evict = (int(parts[2]), int(parts[3])) if len(parts) > 3 else None
     env = dict(kv.split("=", 1) for kv in parts[2].split(";")) if len(parts) == 3 else {}
-    for k in ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC", "RT_AMD_NO_CLUSTERS"):
+    for k in ENV_KNOBS:
         os.environ.pop(k, None)
-    os.environ.update(env)  # read by rt_scene_create
+    os.environ.update(env)  # read by rt_scene_create (and, for some, at every render call: see run())
     path = _capi.PKG_DIR / ("librt_amd.so" if name == "main" else f"variants/librt_amd_{name}.so")
     lib = C.CDLL(str(path))
     lib.rt_last_error.restype = C.c_char_p
@@ -54,7 +55,7 @@ for tag in args.tags.split(","):
     lib_variant = int(var) if var else args.variant
     h = C.c_void_p()
     assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0, lib.rt_last_error()
-    libs[tag] = (lib, h, lib_variant, evict)
+    libs[tag] = (lib, h, lib_variant, evict, env)
 
 out = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -62,7 +63,10 @@ stream = torch.cuda.current_stream().cuda_stream
 
 
 def run(tag, n):
-    lib, h, lib_variant, evict = libs[tag]
+    lib, h, lib_variant, evict, env = libs[tag]
+    for k in ENV_KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
     lib.rt_set_variant(lib_variant)
     if evict is not None:
         lib.rt_set_eviction(*evict)
