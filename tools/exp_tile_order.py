@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Experiment: how much would a cost-descending tile order buy the persistent kernel?  Per-tile cast counts come from a
-first GPU render with per-pixel counting disabled... (here: from the CPU oracle's per-pixel cast counts)."""
+"""Experiment: how much would a better tile order buy the persistent kernel?  The orders tried: the ideal one (tiles by
+descending cast count, taken from the CPU oracle's per-pixel counts), orders a cheap probe could produce (the centre
+pixel's cast count, capped or not; the material its primary ray hits), ascending, and plain image order — handed to the
+kernel through the diagnostic hook rt_diag_set_tile_order.  Results: profiles/README.md."""
 import ctypes as C
 import sys
 import statistics

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Print the kernel timeline of the last frame in a rocprofv3 (rocpd sqlite) kernel trace."""
+"""Print the kernel timeline of the last frame in a rocprofv3 (rocpd sqlite) kernel trace:
+    python tools/wf_timeline.py <results.db> [name of the frame's first kernel, default pwf_init]"""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
-first = sys.argv[2] if len(sys.argv) > 2 else "wf_init"
+first = sys.argv[2] if len(sys.argv) > 2 else "pwf_init"
 rows = db.execute("select name, start, end, grid_x from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if first in r[0]]
 last = rows[idx[-1]:]
