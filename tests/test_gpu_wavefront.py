@@ -133,3 +133,26 @@ def test_clustered_objects_degenerate_rays(seed, eye, variant):
     world = _scenes.clustered_world(seed, n_boxes=5, axis_aligned=True)
     for w, h in ((64, 64), (65, 33)):  # even sizes put clip_x == 0 / clip_y == 0 on pixel centres
         _check(world, _scenes.axis_camera(eye), rt.Frame.full(w, h, 5), budget=16, variant=variant)
+
+
+def test_two_streams_render_concurrently_with_their_own_workspaces(ref):
+    """A scene may be rendered from several streams at once; each stream has its own arenas."""
+    import torch
+
+    world, cam, scene = ref
+    frames = [rt.Frame.full(320, 240, 6), rt.Frame.full(257, 199, 8)]
+    want = [rt.render_whitted(scene, cam, f).clone() for f in frames]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros_like(w) for w in want]
+    for _ in range(5):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for k in range(2):
+            for _rep in range(3):  # back to back on each stream, interleaved between the streams
+                rt.render_whitted(scene, cam, frames[k], out=outs[k], stream=streams[k])
+                rt.render_whitted(scene, cam, frames[1 - k], out=outs[1 - k], stream=streams[1 - k])
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(outs[k].view(torch.int32), want[k].view(torch.int32))
