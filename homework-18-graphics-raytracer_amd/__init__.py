@@ -255,6 +255,59 @@ def encode_srgb8_device(img, out=None, stream=None):
     return out
 
 
+class PhotonAccumulator:
+    """src/photon.rs:9-34 (defined but unused by the reference's main()): per-pixel running sum and weight,
+    resolved to sum / weight — a true average over the epochs of the stochastic pass, as the alternative to main()'s
+    sum-and-renormalise.  Works on numpy arrays (librt_host.so) or CUDA tensors (librt_amd.so), bit-identically."""
+
+    def __init__(self, rows: int, cols: int, device: str = "cpu"):
+        self.rows, self.cols, self.device = rows, cols, device
+        if device == "cpu":
+            self.sum = np.zeros((rows, cols, 3), dtype=np.float32)
+            self.weight = np.zeros((rows, cols), dtype=np.float32)
+        else:
+            import torch
+
+            self.sum = torch.zeros((rows, cols, 3), dtype=torch.float32, device=device)
+            self.weight = torch.zeros((rows, cols), dtype=torch.float32, device=device)
+
+    def accumulate(self, samples, valid, stream=None) -> None:
+        """accumulate() for every sample whose filter flag is set: samples (n_epochs, rows, cols, 3) f32, valid
+        (n_epochs, rows, cols) u8 — the `samples` / `valid` outputs of render_distributed — in epoch order."""
+        n_epochs = int(samples.shape[0])
+        assert tuple(samples.shape) == (n_epochs, self.rows, self.cols, 3) and tuple(valid.shape) == (n_epochs, self.rows, self.cols)
+        n_pixels = self.rows * self.cols
+        if self.device == "cpu":
+            assert samples.dtype == np.float32 and valid.dtype == np.uint8 and samples.flags.c_contiguous and valid.flags.c_contiguous
+            _capi.host_lib().rt_accumulate(samples.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p), n_epochs, n_pixels,
+                                           self.sum.ctypes.data_as(C.c_void_p), self.weight.ctypes.data_as(C.c_void_p))
+        else:
+            import torch
+
+            assert samples.is_cuda and samples.dtype == torch.float32 and samples.is_contiguous()
+            assert valid.is_cuda and valid.dtype == torch.uint8 and valid.is_contiguous()
+            s = stream if stream is not None else torch.cuda.current_stream()
+            _capi.check(_capi.amd_lib().rt_accumulate_device(C.c_void_p(samples.data_ptr()), C.c_void_p(valid.data_ptr()), n_epochs, n_pixels,
+                                                            C.c_void_p(self.sum.data_ptr()), C.c_void_p(self.weight.data_ptr()),
+                                                            C.c_void_p(s.cuda_stream)))
+
+    def resolve(self, stream=None):
+        """into_rgb_internal: sum / weight, black where nothing was accumulated."""
+        n_pixels = self.rows * self.cols
+        if self.device == "cpu":
+            out = np.empty((self.rows, self.cols, 3), dtype=np.float32)
+            _capi.host_lib().rt_accumulator_resolve(self.sum.ctypes.data_as(C.c_void_p), self.weight.ctypes.data_as(C.c_void_p), n_pixels,
+                                                    out.ctypes.data_as(C.c_void_p))
+            return out
+        import torch
+
+        out = torch.empty((self.rows, self.cols, 3), dtype=torch.float32, device=self.device)
+        s = stream if stream is not None else torch.cuda.current_stream()
+        _capi.check(_capi.amd_lib().rt_accumulator_resolve_device(C.c_void_p(self.sum.data_ptr()), C.c_void_p(self.weight.data_ptr()), n_pixels,
+                                                                 C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return out
+
+
 def post_process(img: np.ndarray) -> float:
     """In-place p99-luma normalisation, src/main.rs:748-762.  Returns the divisor (0 = untouched)."""
     assert img.dtype == np.float32 and img.flags.c_contiguous and img.shape[-1] == 3

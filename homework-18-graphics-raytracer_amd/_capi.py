@@ -126,13 +126,13 @@ AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
     "rt_get_variant", "rt_set_eviction", "rt_set_wavefront_budget", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
-    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_post_process_device", "rt_encode_srgb8_device",
+    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_post_process_device", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
     "rt_world_push_light", "rt_world_push_flat_triangle", "rt_world_push_square", "rt_world_load_obj",
     "rt_world_build_reference_scene", "rt_reference_camera", "rt_world_desc", "rt_frame_full", "rt_post_process",
-    "rt_encode_srgb8", "rt_write_png", "rt_host_last_error",
+    "rt_encode_srgb8", "rt_accumulate", "rt_accumulator_resolve", "rt_write_png", "rt_host_last_error",
 ]
 
 _amd = None
@@ -171,6 +171,10 @@ def host_lib() -> C.CDLL:
         lib.rt_post_process.restype = C.c_float
         lib.rt_encode_srgb8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.rt_encode_srgb8.restype = None
+        lib.rt_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.rt_accumulate.restype = None
+        lib.rt_accumulator_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.rt_accumulator_resolve.restype = None
         lib.rt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.rt_host_last_error.restype = C.c_char_p
         _host = lib
@@ -202,6 +206,8 @@ def amd_lib() -> C.CDLL:
         lib.rt_set_variant.argtypes = [C.c_int]
         lib.rt_post_process_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_encode_srgb8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.rt_accumulate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_accumulator_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_rng_create.argtypes = [C.POINTER(Frame), C.POINTER(C.c_void_p)]
         lib.rt_rng_destroy.argtypes = [C.c_void_p]
         lib.rt_rng_download.argtypes = [C.c_void_p, C.c_void_p]

@@ -387,6 +387,31 @@ float rt_post_process(float *rgb, size_t n_pixels) {
 }
 
 /* image.rs:55-66: Linear -> sRGB transfer, then f32 -> u8 (x*255, clamp, truncate) */
+/* photon.rs:25-28, once per surviving sample, epoch by epoch */
+void rt_accumulate(const float *samples, const uint8_t *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight) {
+    for (uint32_t e = 0; e < n_epochs; ++e) {
+        const float *s = samples + (size_t)e * n_pixels * 3;
+        const uint8_t *v = valid + (size_t)e * n_pixels;
+        for (size_t i = 0; i < n_pixels; ++i) {
+            if (!v[i]) continue;
+            sum[3 * i] = sum[3 * i] + s[3 * i];
+            sum[3 * i + 1] = sum[3 * i + 1] + s[3 * i + 1];
+            sum[3 * i + 2] = sum[3 * i + 2] + s[3 * i + 2];
+            weight[i] += 1.0f;
+        }
+    }
+}
+
+/* photon.rs:15-23 */
+void rt_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb) {
+    for (size_t i = 0; i < n_pixels; ++i) {
+        const bool empty = weight[i] < 1.1920928955078125e-7f; /* std::f32::EPSILON */
+        rgb[3 * i] = empty ? 0.0f : sum[3 * i] / weight[i];
+        rgb[3 * i + 1] = empty ? 0.0f : sum[3 * i + 1] / weight[i];
+        rgb[3 * i + 2] = empty ? 0.0f : sum[3 * i + 2] / weight[i];
+    }
+}
+
 void rt_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out) {
     if (!rgb || !out) return;
     for (size_t i = 0; i < n_values; ++i) {

@@ -778,6 +778,21 @@ int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void
     return RT_OK;
 }
 
+int rt_accumulate_device(const float *d_samples, const unsigned char *d_valid, uint32_t n_epochs, size_t n_pixels, float *d_sum,
+                         float *d_weight, void *hip_stream) {
+    if (!d_samples || !d_valid || !d_sum || !d_weight) return fail(RT_ERR_INVALID_ARGUMENT, "rt_accumulate_device: null argument");
+    const hipError_t e = rt::launch_accumulate(d_samples, d_valid, n_epochs, n_pixels, d_sum, d_weight, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_accumulate_device: launch", e);
+    return RT_OK;
+}
+
+int rt_accumulator_resolve_device(const float *d_sum, const float *d_weight, size_t n_pixels, float *d_rgb, void *hip_stream) {
+    if (!d_sum || !d_weight || !d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_accumulator_resolve_device: null argument");
+    const hipError_t e = rt::launch_accumulator_resolve(d_sum, d_weight, n_pixels, d_rgb, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_accumulator_resolve_device: launch", e);
+    return RT_OK;
+}
+
 int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream) {
     if (!d_rgb || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_encode_srgb8_device: null argument");
     hipError_t e = rt::launch_encode_srgb8(d_rgb, n_values, d_out, static_cast<hipStream_t>(hip_stream));

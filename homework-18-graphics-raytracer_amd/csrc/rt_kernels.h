@@ -134,6 +134,9 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,
                                float *divisor_out, hipStream_t stream);
 hipError_t launch_encode_srgb8(const float *rgb, size_t n_values, unsigned char *out, hipStream_t stream);
+hipError_t launch_accumulate(const float *samples, const unsigned char *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight,
+                             hipStream_t stream);
+hipError_t launch_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb, hipStream_t stream);
 
 /* diagnostics: evaluate rt_detmath on the device (op codes = rt_math_op) */
 hipError_t launch_math_eval(int op, const float *d_x, const float *d_y, float *d_out, size_t n, hipStream_t stream);

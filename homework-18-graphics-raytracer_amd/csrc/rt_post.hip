@@ -112,6 +112,39 @@ __global__ void encode_srgb8_kernel(const float *__restrict__ rgb, size_t n_valu
     }
 }
 
+/* PhotonAccumulator::accumulate (photon.rs:25-28) for the samples that passed the filter, epochs in order; one thread
+ * per pixel, so a pixel's additions happen in the reference's order */
+__global__ void accumulate_kernel(const float *__restrict__ samples, const unsigned char *__restrict__ valid, uint32_t n_epochs,
+                                  size_t n_pixels, float *__restrict__ sum, float *__restrict__ weight) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += stride) {
+        float s0 = sum[3 * i], s1 = sum[3 * i + 1], s2 = sum[3 * i + 2], w = weight[i];
+        for (uint32_t e = 0; e < n_epochs; ++e) {
+            if (valid[(size_t)e * n_pixels + i] == 0u) continue;
+            const float *ph = samples + ((size_t)e * n_pixels + i) * 3u;
+            s0 = s0 + ph[0];
+            s1 = s1 + ph[1];
+            s2 = s2 + ph[2];
+            w += 1.0f;
+        }
+        sum[3 * i] = s0; sum[3 * i + 1] = s1; sum[3 * i + 2] = s2;
+        weight[i] = w;
+    }
+}
+
+/* into_rgb_internal (photon.rs:15-23) */
+__global__ void accumulator_resolve_kernel(const float *__restrict__ sum, const float *__restrict__ weight, size_t n_pixels,
+                                           float *__restrict__ rgb) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += stride) {
+        const float w = weight[i];
+        const bool empty = w < 1.1920928955078125e-7f; /* std::f32::EPSILON */
+        rgb[3 * i] = empty ? 0.0f : sum[3 * i] / w;
+        rgb[3 * i + 1] = empty ? 0.0f : sum[3 * i + 1] / w;
+        rgb[3 * i + 2] = empty ? 0.0f : sum[3 * i + 2] / w;
+    }
+}
+
 static unsigned grid_for(size_t n) {
     size_t b = (n + 255) / 256;
     if (b > 2048) b = 2048; /* grid-stride the rest (memory-bound: 256 CUs x 8 blocks) */
@@ -133,6 +166,19 @@ hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row
         hipLaunchKernelGGL(post_pick_kernel, dim3(1), dim3(64), 0, stream, pass, state);
     }
     hipLaunchKernelGGL(post_scale_kernel, dim3(grid_for(n_pixels * 3)), dim3(256), 0, stream, rgb, n_pixels * 3, state, divisor_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(const float *samples, const unsigned char *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight,
+                             hipStream_t stream) {
+    if (n_pixels == 0 || n_epochs == 0) return hipSuccess;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, samples, valid, n_epochs, n_pixels, sum, weight);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb, hipStream_t stream) {
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(accumulator_resolve_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, sum, weight, n_pixels, rgb);
     return hipGetLastError();
 }
 

@@ -226,6 +226,14 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
 int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void *hip_stream);
 /* Image::<Srgb<u8>>::convert_from (src/image.rs:55-66): linear f32 -> sRGB-encoded u8, n_values = 3*pixels. */
 int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream);
+/* PhotonAccumulator (src/photon.rs:9-34; unused by the reference's main()) on the device, bit-identical to
+ * rt_accumulate / rt_accumulator_resolve in librt_host.so: d_sum (3 f32 per pixel) and d_weight (1 f32 per pixel) start
+ * at zero; rt_accumulate_device applies accumulate() for every sample whose filter flag is set (d_samples, d_valid: the
+ * n_epochs x n_pixels outputs of rt_render_distributed), in epoch order; rt_accumulator_resolve_device writes
+ * sum / weight, black while weight < f32::EPSILON.  Stream-ordered. */
+int rt_accumulate_device(const float *d_samples, const unsigned char *d_valid, uint32_t n_epochs, size_t n_pixels, float *d_sum,
+                         float *d_weight, void *hip_stream);
+int rt_accumulator_resolve_device(const float *d_sum, const float *d_weight, size_t n_pixels, float *d_rgb, void *hip_stream);
 
 /* ---- diagnostics ------------------------------------------------------------ */
 

@@ -74,6 +74,14 @@ float rt_post_process(float *rgb, size_t n_pixels);
 /* Linear f32 -> sRGB-encoded u8 (n_values = 3 * pixels). */
 void rt_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out);
 
+/* PhotonAccumulator (src/photon.rs:9-34; defined but never used by the reference's main(): SURVEY §8f-4) — a true
+ * running average as the alternative to main()'s sum-and-renormalise.  `sum` (3 f32 per pixel) and `weight` (1 f32 per
+ * pixel) start at zero.  rt_accumulate applies accumulate() — sum = sum + photon, weight_sum += 1.0 — for every sample
+ * whose filter flag is set (`samples`, `valid`: the n_epochs x n_pixels outputs of rt_render_distributed), in epoch
+ * order; rt_accumulator_resolve is into_rgb_internal: black while weight < f32::EPSILON, else sum / weight. */
+void rt_accumulate(const float *samples, const uint8_t *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight);
+void rt_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb);
+
 /* RGB8 PNG, written to "<path>.tmp" then renamed over path. */
 int rt_write_png(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
 

@@ -1092,6 +1092,28 @@ void orc_luma_row(int luma_mode, float *row3) {
 }
 
 /* image.rs:55-66: into_rgb().into_encoding::<Srgb>().into_format::<u8>() */
+/* photon.rs:25-28 PhotonAccumulator::accumulate, once per surviving sample (the filter of main.rs:1157-1160 decides
+ * which survive), in epoch order */
+void orc_accumulate(const float *samples, const uint8_t *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight) {
+    for (uint32_t e = 0; e < n_epochs; ++e)
+        for (size_t i = 0; i < n_pixels; ++i) {
+            if (!valid[(size_t)e * n_pixels + i]) continue;
+            const float *ph = samples + ((size_t)e * n_pixels + i) * 3;
+            sum[3 * i] = sum[3 * i] + ph[0]; /* self.sum = self.sum + photon */
+            sum[3 * i + 1] = sum[3 * i + 1] + ph[1];
+            sum[3 * i + 2] = sum[3 * i + 2] + ph[2];
+            weight[i] += 1.0f;               /* self.weight_sum += 1.0 */
+        }
+}
+
+/* photon.rs:15-23 into_rgb_internal: black while weight_sum < f32::EPSILON, else sum / weight_sum */
+void orc_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb) {
+    for (size_t i = 0; i < n_pixels; ++i) {
+        const bool empty = weight[i] < F_EPSILON;
+        for (int c = 0; c < 3; ++c) rgb[3 * i + c] = empty ? 0.0f : sum[3 * i + c] / weight[i];
+    }
+}
+
 void orc_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out) {
     for (size_t i = 0; i < n_values; ++i) {
         float x = rgb[i];

@@ -66,6 +66,9 @@ void orc_render_whitted_counts(const rt_scene_desc *scene, const rt_camera *came
 float orc_post_process(float *rgb, size_t n_pixels, int luma_mode);
 void orc_luma_row(int luma_mode, float *row3);
 void orc_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out);
+/* PhotonAccumulator (src/photon.rs:9-34): accumulate() for every sample whose flag is set, epoch by epoch; resolve */
+void orc_accumulate(const float *samples, const uint8_t *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight);
+void orc_accumulator_resolve(const float *sum, const float *weight, size_t n_pixels, float *rgb);
 
 size_t orc_rng_state_words(void);
 void orc_rng_init(const rt_frame *frame, uint32_t *states);

@@ -72,6 +72,10 @@ def lib(kind: str = "detmath") -> C.CDLL:
         l.orc_luma_row.restype = None
         l.orc_encode_srgb8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         l.orc_encode_srgb8.restype = None
+        l.orc_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.orc_accumulate.restype = None
+        l.orc_accumulator_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.orc_accumulator_resolve.restype = None
         _libs[kind] = l
     return _libs[kind]
 
@@ -152,3 +156,15 @@ def render_distributed(desc, camera, frame, rng_states, n_epochs, focus=3.0, blu
     l.orc_render_distributed(C.byref(desc), C.byref(camera), C.byref(frame), focus, blur, rng_states.ctypes.data, n_epochs,
                              samples.ctypes.data, valid.ctypes.data, C.byref(casts), threads)
     return samples, valid, int(casts.value)
+
+
+def accumulate(samples: np.ndarray, valid: np.ndarray, sum_: np.ndarray, weight: np.ndarray) -> None:
+    """PhotonAccumulator::accumulate over (n_epochs, rows, cols[, 3]) arrays, in place (photon.rs:25-28)."""
+    n_epochs = samples.shape[0]
+    lib().orc_accumulate(samples.ctypes.data, valid.ctypes.data, n_epochs, weight.size, sum_.ctypes.data, weight.ctypes.data)
+
+
+def accumulator_resolve(sum_: np.ndarray, weight: np.ndarray) -> np.ndarray:
+    out = np.empty_like(sum_)
+    lib().orc_accumulator_resolve(sum_.ctypes.data, weight.ctypes.data, weight.size, out.ctypes.data)
+    return out
