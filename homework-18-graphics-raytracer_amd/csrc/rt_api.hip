@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -42,6 +43,8 @@ struct Workspace {
     size_t tiles_n = 0;
     void *d_pwf = nullptr; /* persistent-wavefront path: global words + one arena per workgroup */
     size_t pwf_bytes = 0;
+    void *d_split = nullptr; /* split distributed pass: requests, shades and frames of one batch of epochs */
+    size_t split_bytes = 0;
 };
 
 struct rt_scene {
@@ -57,6 +60,11 @@ struct rt_scene {
 static int g_evict_threshold = -1, g_evict_min_iter = -1;
 static int g_wf_nodes_per_pixel = -1;
 static const uint32_t *g_diag_tile_order = nullptr;
+#ifndef RT_DIST_SPLIT_DEFAULT
+#define RT_DIST_SPLIT_DEFAULT 1
+#endif
+static int g_dist_split = -1; /* -1: RT_AMD_DIST_SPLIT or the default */
+extern "C" int rt_set_distributed_split(int on) { g_dist_split = on < 0 ? -1 : (on ? 1 : 0); return 0; }
 extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order = static_cast<const uint32_t *>(device_ptr); }
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
@@ -426,6 +434,7 @@ int rt_scene_destroy(rt_scene *scene) {
         if (kv.second.d_cont) (void)hipFree(kv.second.d_cont);
         if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
         if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
+        if (kv.second.d_split) (void)hipFree(kv.second.d_split);
     }
     if (scene->d_blob) e = hipFree(scene->d_blob);
     delete scene;
@@ -725,10 +734,69 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.work_queue = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
+    int split = g_dist_split;
+    if (split < 0) {
+        const char *v = getenv("RT_AMD_DIST_SPLIT");
+        split = v && *v ? (*v != '0') : RT_DIST_SPLIT_DEFAULT;
+    }
+    const size_t n_pixels = (size_t)kf.cols * kf.rows;
+    if (n_pixels == 0 || n_epochs == 0) return RT_OK;
+    rt_scene *mut = const_cast<rt_scene *>(scene);
+    if (split && kf.max_depth <= 254) {
+        /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
+         * many epochs as fit the workspace cap (RT_AMD_DIST_WS_MB, default 8 GiB; one epoch at least) */
+        size_t cap = (size_t)8192 << 20;
+        if (const char *v = getenv("RT_AMD_DIST_WS_MB")) {
+            if (*v) cap = (size_t)strtoull(v, nullptr, 10) << 20;
+        }
+        const uint32_t slots = (uint32_t)(kf.max_depth > 0 ? kf.max_depth : 0) + 1u;
+        const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
+        uint32_t batch = (uint32_t)std::min<size_t>(n_epochs, std::max<size_t>(1, cap / per_epoch));
+        auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
+        const size_t n_samples = n_pixels * batch;
+        size_t off = 0;
+        const size_t o_hdr = carve(off, n_samples * sizeof(uint32_t));
+        const size_t o_req = carve(off, n_samples * slots * 4u * sizeof(uint4));
+        const size_t o_shade = carve(off, n_samples * slots * sizeof(float4));
+        const size_t o_frame = carve(off, n_samples * (slots - 1u) * sizeof(float4));
+        char *base = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(mut->ws_mutex);
+            Workspace &ws = mut->workspaces[stream];
+            if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
+            if (ws.split_bytes < off) {
+                if (ws.d_split) {
+                    RT_HIP(hipStreamSynchronize(stream));
+                    RT_HIP(hipFree(ws.d_split));
+                    ws.d_split = nullptr;
+                    ws.split_bytes = 0;
+                }
+                RT_HIP(hipMalloc(&ws.d_split, off));
+                ws.split_bytes = off;
+            }
+            dp.work_queue = ws.d_counters;
+            base = static_cast<char *>(ws.d_split);
+        }
+        dp.sp_hdr = reinterpret_cast<uint32_t *>(base + o_hdr);
+        dp.sp_req = reinterpret_cast<uint4 *>(base + o_req);
+        dp.sp_shade = reinterpret_cast<float4 *>(base + o_shade);
+        dp.sp_frame = reinterpret_cast<float4 *>(base + o_frame);
+        dp.sp_slots = slots;
+        for (uint32_t e0 = 0; e0 < n_epochs; e0 += batch) {
+            /* the layout is [slot][sample of THIS batch]: a short last batch just uses a prefix of every array */
+            dp.epoch0 = e0;
+            dp.n_epochs = std::min(batch, n_epochs - e0);
+            hipError_t e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+            if (e == hipSuccess) e = rt::launch_distributed_split(scene->ks, kf, dp, dist_waves, stream);
+            if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
+        }
+        return RT_OK;
+    }
+    dp.epoch0 = 0;
+    dp.sp_hdr = nullptr; dp.sp_req = nullptr; dp.sp_shade = nullptr; dp.sp_frame = nullptr; dp.sp_slots = 0;
     {
         const char *v = getenv("RT_AMD_DIST_STATIC"); /* A/B: one 64-pixel chunk per wave instead of persistent lanes */
         if (!(v && *v == '1')) {
-            rt_scene *mut = const_cast<rt_scene *>(scene);
             std::lock_guard<std::mutex> lock(mut->ws_mutex);
             Workspace &ws = mut->workspaces[stream];
             if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));

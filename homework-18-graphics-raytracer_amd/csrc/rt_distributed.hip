@@ -567,4 +567,425 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
     return hipGetLastError();
 }
 
+
+/* ---- the split pass ----------------------------------------------------------------------------------------------
+ * distributed_kernel above keeps a lane on one pixel through everything a sample needs: the scatter chain, every
+ * get_shade along it (three shadow casts each) and the unwind — 168 VGPRs with 76 of them spilled, three waves per
+ * SIMD, lanes in six different phases.  But get_shade draws no random numbers and the chain does not wait for it:
+ * get_shade(&next_hit) is only needed when the level returns (main.rs:565-571, 584-590, 604-605).  So the pass is cut
+ * in three:
+ *
+ *   dist_chain_kernel   the chain alone — shoot_focus, the casts of the scattered/refracted rays, weighted_select,
+ *                       scatter_hit, the per-level factor (brdf or decay) — all the random draws, in the reference's
+ *                       order; per sample it records the get_shade REQUESTS (hit + view direction) and the frames;
+ *   dist_shade_kernel   every request of the batch: get_shade (main.rs:407-464) with a wave-uniform light index — the
+ *                       organisation of the Whitted path's SHADE items;
+ *   dist_unwind_kernel  per pixel, the batch's epochs in order: the unwind of main.rs:571/590/605 over the recorded
+ *                       frames, the sample filter (main.rs:1157-1160) and `img += photon` (main.rs:1165).
+ *
+ * Same operations on the same values as the fused kernel, so samples, flags, RNG states and cast counts are
+ * bit-identical to it and to the oracle (tests/test_gpu_distributed_parity.py runs both). */
+
+#ifndef RT_DIST_CHAIN_MIN_WAVES
+#define RT_DIST_CHAIN_MIN_WAVES 4
+#endif
+
+__device__ __forceinline__ uint32_t dfu(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float duf(uint32_t x) { return __uint_as_float(x); }
+
+template <int DUMMY>
+__global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_slots = fr.cols * fr.rows;
+    const uint32_t band_slots = fr.cols << 3;
+    const size_t n_pixels = total_slots;
+    const size_t n_samples = n_pixels * dp.n_epochs; /* of this batch */
+    uint32_t q_next = 0u, q_end = 0u;
+    bool exhausted = false;
+    uint32_t out_index = 0u;
+    float clip_x = 0.0f, clip_y = 0.0f;
+    const V3 cam_x = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
+    const V3 cam_y = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
+    const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
+    const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
+
+    Rng rng;
+    rng.st = dp.rng_states;
+    rng.index = 256u;
+    uint32_t phase = DP_DONE;
+    uint32_t epoch = 0u;
+    Ray req;
+    req.o = v3(0.0f, 0.0f, 0.0f);
+    req.d = v3(0.0f, 0.0f, 1.0f);
+    req.mode = FACE_FRONT;
+    req.excl = 0u;
+    uint32_t casts = 0u;
+    HitGeom h;
+    h.pos = h.normal = v3(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.prim = h.bf = h.obj = 0u;
+    V3 h_in_dir = v3(0.0f, 0.0f, 0.0f);
+    uint32_t h_in_mode = FACE_FRONT;
+    V3 sdir = v3(0.0f, 0.0f, 0.0f);
+    uint32_t kind = 0u;
+    int32_t sp = 0; /* frames recorded so far = the level */
+    float travel = 0.0f;
+    int32_t retry = 0;
+
+    auto start_epoch = [&]() { /* Camera::shoot_focus (main.rs:101-127) */
+        const V3 direction = normalize(clip_x * cam_x + clip_y * cam_y + cam_t);
+        const float xoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng));
+        const float yoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng));
+        req.d = normalize(direction * dp.focus + cam_x * xoffset + cam_y * yoffset);
+        req.o = cam_o - (cam_x * xoffset + cam_y * yoffset);
+        req.mode = FACE_FRONT;
+        req.excl = 0u;
+        sp = 0;
+        phase = DP_PRIMARY;
+    };
+    /* get_shade(&h') with h' = h seen along `view` is due: leave it to dist_shade_kernel, in request slot sp */
+    auto emit_request = [&](V3 view) {
+        const size_t s = (size_t)epoch * n_pixels + out_index;
+        uint4 *r = dp.sp_req + ((size_t)sp * n_samples + s) * 4u;
+        r[0] = make_uint4(dfu(h.pos.x), dfu(h.pos.y), dfu(h.pos.z), dfu(h.u));
+        r[1] = make_uint4(dfu(h.normal.x), dfu(h.normal.y), dfu(h.normal.z), dfu(h.v));
+        r[2] = make_uint4(dfu(view.x), dfu(view.y), dfu(view.z), h.obj);
+        r[3] = make_uint4(h.prim, 0u, 0u, 0u);
+    };
+
+    for (;;) {
+        unsigned long long need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
+        if (dp.n_epochs == 0u) need = 0ull;
+        while (need != 0ull) {
+            if (q_next == q_end) {
+                if (exhausted) break;
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(dp.work_queue, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c * 64u >= total_slots) { exhausted = true; break; }
+                q_next = c * 64u;
+                q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t avail = q_end - q_next;
+            if (phase == DP_DONE && rank < avail) {
+                const uint32_t slot = q_next + rank;
+                const uint32_t band = slot / band_slots;
+                const uint32_t r = slot - band * band_slots;
+                const uint32_t rows_left = fr.rows - (band << 3);
+                const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
+                const uint32_t col = r / band_rows;
+                const uint32_t row = (band << 3) + (r - col * band_rows);
+                out_index = row * fr.cols + col;
+                const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
+                clip_y = (fr.half_height - (float)y) / fr.height_f;
+                clip_x = ((float)x - fr.half_width) / fr.height_f;
+                rng.st = dp.rng_states + (size_t)out_index * RNG_WORDS;
+                rng.index = rng.st[RNG_INDEX];
+                epoch = 0u;
+                start_epoch();
+            }
+            const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
+            q_next += n_need < avail ? n_need : avail;
+            need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
+        }
+        if (__builtin_amdgcn_ballot_w64(phase != DP_DONE) == 0ull) break;
+
+        CastResult cr;
+        cr.prim = -1;
+        cr.t = 0.0f;
+        cr.bf = 0u;
+        cr.a0 = cr.a1 = cr.a2 = 0.0f;
+        if (phase != DP_DONE) {
+            cr = cast_asm(sc, req);
+            casts += 1u;
+        }
+        if (phase == DP_DONE) continue;
+
+        enum { GO_LEVEL, GO_TRY_EXIT, GO_END } go = GO_END;
+        bool terminal = false; /* the sample's value is a get_shade (request slot sp); else black */
+        HitGeom ih = h;
+        V3 i_in_dir = req.d;
+        uint32_t i_in_mode = req.mode;
+
+        if (phase == DP_PRIMARY) {
+            if (cr.prim >= 0) { /* a miss: black (main.rs:1154) */
+                h = finish_hit(sc, req, cr, false);
+                h_in_dir = req.d;
+                h_in_mode = req.mode;
+                go = GO_LEVEL;
+            }
+        } else if (phase == DP_NEXT) {
+            if (cr.prim < 0) {
+                if (kind != 2u) { /* get_shade(&scattered_hit): the same hit seen along the scattered direction (main.rs:573, 592) */
+                    emit_request(sdir);
+                    terminal = true;
+                } /* kind 2: black (main.rs:606-608) */
+            } else {
+                /* the level's factor, before `h` moves on to the next hit (main.rs:566-570, 585-589, 605) */
+                V3 factor;
+                if (kind == 2u) {
+                    factor = v3(rtdm::powf(sc.materials[h.obj].opaque_decay, travel), 0.0f, 0.0f);
+                } else {
+                    const Mat m = material_approx(sc.materials[h.obj], h.u, h.v);
+                    const V3 view = -h_in_dir;
+                    factor = kind == 0u ? get_diffuse(m, h.normal, req.d) : get_specular(m, h.normal, view, req.d);
+                }
+                dp.sp_frame[(size_t)sp * n_samples + (size_t)epoch * n_pixels + out_index] = make_float4(factor.x, factor.y, factor.z, duf(kind));
+                h = finish_hit(sc, req, cr, false);
+                h_in_dir = req.d;
+                h_in_mode = req.mode;
+                emit_request(req.d); /* get_shade(&next_hit) (main.rs:565, 584, 604): frame sp's shade */
+                sp += 1;
+                go = GO_LEVEL;
+            }
+        } else { /* DP_REFR_INSIDE / DP_REFR_BOUNCE; a miss is Refraction::Infinite -> black (main.rs:610) */
+            if (cr.prim >= 0) {
+                ih = finish_hit(sc, req, cr, false);
+                i_in_dir = req.d;
+                i_in_mode = req.mode;
+                if (phase == DP_REFR_INSIDE) {
+                    travel = distance(ih.pos, h.pos);
+                    retry = 0;
+                } else {
+                    travel += distance(req.o, ih.pos);
+                    retry += 1;
+                }
+                go = GO_TRY_EXIT;
+            }
+        }
+
+        bool casting = false;
+        if (go == GO_LEVEL) {
+            /* distributed_ray_trace(state, &h), depth = max_depth - sp */
+            const int32_t depth = fr.max_depth - sp;
+            if (depth <= 0) { /* main.rs:524-527: get_shade(&hit) */
+                emit_request(h_in_dir);
+                terminal = true;
+            } else {
+                const rt_material &rm = sc.materials[h.obj];
+                /* weighted_select (main.rs:652-666) */
+                const float w0 = (1.0f - rm.shiness) * (1.0f - rm.transparency);
+                const float w1 = rm.shiness * (1.0f - rm.transparency);
+                const float w2 = rm.transparency;
+                float wsum = 0.0f;
+                wsum = wsum + w0;
+                wsum = wsum + w1;
+                wsum = wsum + w2;
+                const float rsel = gen_range_f32(rng, 0.0f, wsum);
+                float acc = 0.0f;
+                acc += w0;
+                kind = 2u;
+                if (rsel < acc) kind = 0u;
+                else {
+                    acc += w1;
+                    if (rsel < acc) kind = 1u;
+                }
+                /* scatter_hit (main.rs:539-554) */
+                const float exponent = kind == 0u ? 1.0f : rm.smoothness;
+                const V3 lobe = kind == 0u ? -h.normal : h_in_dir;
+                const float phi = rtdm::acosf(rtdm::powf(1.0f - gen_range_f32(rng, 0.0f, 1.0f), exponent));
+                const float theta = gen_range_f32(rng, -RT_F_PI, RT_F_PI);
+                const float sphi = rtdm::sinf(phi), cphi = rtdm::cosf(phi);
+                sdir = adjust_normal(v3(sphi * rtdm::cosf(theta), sphi * rtdm::sinf(theta), cphi), normalize(lobe));
+                const float cosine = -dot(h.normal, sdir);
+                if (!(cosine <= 0.0f)) { /* else black (main.rs:560, 579, 598) */
+                    if (kind != 2u) { /* get_reflect(&scattered_hit) (main.rs:328-341) */
+                        req.o = h.pos;
+                        req.d = reflect_dir(h.normal, sdir);
+                        req.mode = h_in_mode;
+                        req.excl = pack_excl(h.prim, h.bf ? FACE_FRONT : FACE_BACK);
+                        phase = DP_NEXT;
+                        casting = true;
+                    } else { /* get_refract(&scattered_hit, 100.0) (main.rs:343-405); Trapped -> black */
+                        V3 refract_in;
+                        if (refract_dir(h.normal, sdir, rm.refraction_index, &refract_in)) {
+                            req.o = h.pos;
+                            req.d = normalize(refract_in);
+                            req.mode = FACE_BACK;
+                            req.excl = pack_excl(h.prim, FACE_FRONT);
+                            phase = DP_REFR_INSIDE;
+                            casting = true;
+                        }
+                    }
+                }
+            }
+        } else if (go == GO_TRY_EXIT) {
+            const rt_material &rm = sc.materials[h.obj];
+            V3 out_dir;
+            const bool have_out = refract_dir(ih.normal, i_in_dir, 1.0f / rm.refraction_index, &out_dir);
+            if (!have_out && travel <= 100.0f && retry < 10) {
+                req.o = ih.pos;
+                req.d = reflect_dir(ih.normal, i_in_dir);
+                req.mode = i_in_mode;
+                req.excl = pack_excl(ih.prim, ih.bf ? FACE_FRONT : FACE_BACK);
+                phase = DP_REFR_BOUNCE;
+                casting = true;
+            } else if (have_out) { /* escape ray, main.rs:393-401; else Trapped -> black */
+                req.o = ih.pos;
+                req.d = normalize(out_dir);
+                req.mode = FACE_FRONT;
+                req.excl = pack_excl(ih.prim, FACE_BACK);
+                phase = DP_NEXT;
+                casting = true;
+            }
+        }
+        if (!casting) { /* the chain of this (pixel, epoch) is over */
+            dp.sp_hdr[(size_t)epoch * n_pixels + out_index] = (uint32_t)sp | (terminal ? 0x100u : 0u);
+            epoch += 1u;
+            if (epoch < dp.n_epochs) {
+                start_epoch();
+            } else {
+                rng.st[RNG_INDEX] = rng.index; /* park the stream position */
+                phase = DP_DONE;
+            }
+        }
+    }
+
+    if (dp.ray_count != nullptr) {
+        uint32_t c = casts;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0u && c != 0u) atomicAdd(dp.ray_count, (unsigned long long)c);
+    }
+}
+
+/* get_shade (main.rs:407-464) for request slot blockIdx.y of 64 consecutive samples per wave */
+__global__ __launch_bounds__(64, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.y;
+    uint32_t casts = 0u;
+    for (size_t first = (size_t)blockIdx.x * 64u; first < n_samples; first += (size_t)gridDim.x * 64u) {
+        const size_t s = first + lane;
+        bool active = false;
+        if (s < n_samples) {
+            const uint32_t hdr = dp.sp_hdr[s];
+            active = slot < (hdr & 0xffu) + ((hdr >> 8) & 1u);
+        }
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+        V3 pos = v3(0.0f, 0.0f, 0.0f), normal = v3(0.0f, 0.0f, 1.0f), view = v3(0.0f, 0.0f, 1.0f);
+        float u = 0.0f, v = 0.0f;
+        uint32_t obj = 0u, prim = 0u;
+        if (active) {
+            const uint4 *r = dp.sp_req + ((size_t)slot * n_samples + s) * 4u;
+            const uint4 a = r[0], b = r[1], c = r[2], d = r[3];
+            pos = v3(duf(a.x), duf(a.y), duf(a.z)); u = duf(a.w);
+            normal = v3(duf(b.x), duf(b.y), duf(b.z)); v = duf(b.w);
+            view = v3(duf(c.x), duf(c.y), duf(c.z)); obj = c.w;
+            prim = d.x;
+        }
+        const Mat m = material_approx(sc.materials[obj], u, v);
+        const V3 adj_n = adjust_normal(m.normal, normal); /* main.rs:410 */
+        V3 sum = v3(0.0f, 0.0f, 0.0f);
+        for (uint32_t light_i = 0; light_i < sc.n_lights; ++light_i) { /* wave-uniform */
+            const rt_light &L = sc.lights[light_i];
+            DirLight dl;
+            dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
+            bool need = false;
+            if (active && approximate_into_directional(L, pos, &dl)) {
+                const float cosine = -dot(dl.direction, adj_n);
+                need = !(cosine <= 0.0f);
+            }
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+            if (need) {
+                Ray req;
+                req.o = pos;
+                req.d = -dl.direction;
+                req.mode = FACE_BACK;
+                req.excl = pack_excl(prim, FACE_BACK);
+                const CastResult cr = cast_asm(sc, req);
+                casts += 1u;
+                bool lit = true;
+                if (cr.prim >= 0) {
+                    const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
+                    if (has_origin) {
+                        const V3 occ = req.o + req.d * cr.t;
+                        if (distance(pos, occ) < distance(pos, v3(L.origin[0], L.origin[1], L.origin[2]))) lit = false;
+                    } else {
+                        lit = false;
+                    }
+                }
+                if (lit) {
+                    const V3 light_direction = req.d;
+                    const V3 diffuse = get_diffuse(m, adj_n, light_direction) * dl.color;
+                    const V3 specular = get_specular(m, adj_n, -view, light_direction) * dl.color;
+                    sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
+                }
+            }
+        }
+        if (active) dp.sp_shade[(size_t)slot * n_samples + s] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    }
+    if (dp.ray_count != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
+        if (lane == 0u && casts != 0u) atomicAdd(dp.ray_count, (unsigned long long)casts);
+    }
+}
+
+/* the unwind (main.rs:571, 590, 605), the sample filter (main.rs:1157-1160) and the accumulation (main.rs:1165) */
+__global__ __launch_bounds__(256) void dist_unwind_kernel(const DistParams dp, const size_t n_pixels, const size_t call_pixels_stride) {
+    const size_t n_samples = n_pixels * dp.n_epochs;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += (size_t)gridDim.x * blockDim.x) {
+        V3 accum = v3(0.0f, 0.0f, 0.0f);
+        if (dp.accum != nullptr) accum = v3(dp.accum[p * 3u], dp.accum[p * 3u + 1u], dp.accum[p * 3u + 2u]);
+        for (uint32_t e = 0; e < dp.n_epochs; ++e) {
+            const size_t s = (size_t)e * n_pixels + p;
+            const uint32_t hdr = dp.sp_hdr[s];
+            const uint32_t frames = hdr & 0xffu;
+            V3 value = v3(0.0f, 0.0f, 0.0f);
+            if ((hdr >> 8) & 1u) {
+                const float4 t = dp.sp_shade[(size_t)frames * n_samples + s];
+                value = v3(t.x, t.y, t.z);
+            }
+            for (uint32_t k = frames; k-- > 0u;) {
+                const float4 f = dp.sp_frame[(size_t)k * n_samples + s];
+                const float4 sh4 = dp.sp_shade[(size_t)k * n_samples + s];
+                const V3 shade = v3(sh4.x, sh4.y, sh4.z);
+                if (dfu(f.w) == 2u) {
+                    value = (value + shade) * f.x; /* main.rs:605 */
+                } else {
+                    const V3 sc_ = value * v3(f.x, f.y, f.z);  /* main.rs:566, 585 */
+                    value = shade + (sc_ - shade) * 0.5f;       /* palette Mix::mix(&s, 0.5), main.rs:571, 590 */
+                }
+            }
+            const bool ok = rtdm::is_normal(value.x) && rtdm::is_normal(value.y) && rtdm::is_normal(value.z);
+            const size_t o = ((size_t)(dp.epoch0 + e)) * call_pixels_stride + p;
+            if (dp.samples != nullptr) {
+                dp.samples[o * 3u] = value.x;
+                dp.samples[o * 3u + 1u] = value.y;
+                dp.samples[o * 3u + 2u] = value.z;
+            }
+            if (dp.valid != nullptr) dp.valid[o] = ok ? 1 : 0;
+            if (ok) accum = accum + value;
+        }
+        if (dp.accum != nullptr) {
+            dp.accum[p * 3u] = accum.x;
+            dp.accum[p * 3u + 1u] = accum.y;
+            dp.accum[p * 3u + 2u] = accum.z;
+        }
+    }
+}
+
+size_t distributed_split_bytes_per_sample(int32_t max_depth) {
+    const size_t d = (size_t)(max_depth > 0 ? max_depth : 0);
+    return sizeof(uint32_t) + (d + 1u) * (4u * sizeof(uint4) + sizeof(float4)) + d * sizeof(float4);
+}
+
+/* one batch of dp.n_epochs epochs (dp.epoch0 = its first epoch within the call); dp.work_queue zeroed */
+hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
+    const uint32_t total = fr.cols * fr.rows;
+    if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
+    uint32_t waves = (total + 63u) / 64u;
+    const uint32_t chain_waves = resident_waves / 3u * (uint32_t)RT_DIST_CHAIN_MIN_WAVES; /* resident_waves is sized for 3 per SIMD */
+    if (waves > chain_waves) waves = chain_waves;
+    hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    const size_t n_samples = (size_t)total * dp.n_epochs;
+    const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
+    size_t shade_waves = (n_samples + 63u) / 64u;
+    if (shade_waves > 65536u) shade_waves = 65536u;
+    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_waves, slots), dim3(64), 0, stream, sc, dp, n_samples);
+    size_t blocks = ((size_t)total + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(dist_unwind_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp, (size_t)total, (size_t)total);
+    return hipGetLastError();
+}
+
 } /* namespace rt */

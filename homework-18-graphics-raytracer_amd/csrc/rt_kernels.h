@@ -125,10 +125,20 @@ struct DistParams {
     unsigned char *valid;          /* n_epochs*pixels filter flags; may be null */
     unsigned long long *ray_count; /* may be null */
     uint32_t *work_queue;          /* zeroed chunk counter: persistent lanes; null: one chunk per wave */
+    /* split pass (launch_distributed_split): the chain kernel records, per sample of the batch, what the shade and
+     * unwind kernels need; all arrays are slot-major ([slot][sample]) so that neighbouring lanes read neighbouring records */
+    uint32_t epoch0;               /* first epoch of this batch within the call (indexes samples/valid) */
+    uint32_t *sp_hdr;              /* [sample] frames | has_terminal << 8 */
+    uint4 *sp_req;                 /* [slot][sample] x 4: get_shade requests (hit, view direction) */
+    float4 *sp_shade;              /* [slot][sample]: get_shade results */
+    float4 *sp_frame;              /* [level][sample]: factor.xyz, kind */
+    uint32_t sp_slots;             /* max_depth + 1 */
 };
+size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u
 hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t stream);
 hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
+hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
 
 /* post_process / sRGB encode on the device (rt_post.hip) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,

@@ -1,12 +1,24 @@
 """GPU parity of the distributed (stochastic / DoF) pass: samples, filter flags, RNG states and cast counts
-of the HIP kernel against the oracle, bit for bit, for the same seeds (y*2^33 + x)."""
+of the HIP kernels against the oracle, bit for bit, for the same seeds (y*2^33 + x) — for both organisations of the
+pass (rt_set_distributed_split: chain / shade / unwind kernels, the default, and the single fused kernel)."""
+import os
+
 import numpy as np
 import pytest
 
 import homework_18_graphics_raytracer_amd as rt
+from homework_18_graphics_raytracer_amd import _capi
 import _oracle
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=[1, 0], ids=["split", "fused"])
+def organisation(request):
+    lib = _capi.amd_lib()
+    lib.rt_set_distributed_split(request.param)
+    yield request.param
+    lib.rt_set_distributed_split(-1)
 
 
 @pytest.fixture(scope="module")
@@ -45,6 +57,47 @@ def test_distributed_bit_exact(ctx, w, h, depth, epochs):
     assert not bad.any(), f"{bad.sum()} channels differ, first at {np.argwhere(bad)[:3].tolist()}"
     assert casts == wcasts
     assert np.array_equal(rng.download(), st)  # same number of draws everywhere: the streams stay in step
+
+
+@pytest.mark.parametrize("cap_mb,epochs", [("1", 3), ("8", 3), ("8", 5)])
+def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs):
+    """A small workspace cap makes the split pass run the call in batches (1 epoch; 2 + a short last one)."""
+    if not organisation:
+        pytest.skip("the fused kernel has no workspace")
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame.full(96, 72, 5)
+    accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    os.environ["RT_AMD_DIST_WS_MB"] = cap_mb
+    try:
+        rng, s, v, casts = _run_gpu(scene, camera, frame, epochs, accum=accum)
+    finally:
+        del os.environ["RT_AMD_DIST_WS_MB"]
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, epochs)
+    assert np.array_equal(v, wv) and np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+    want = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+    for e in range(epochs):
+        want = np.where(wv[e][..., None] != 0, want + ws[e], want)
+    assert np.array_equal(accum.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_accumulate_only_call_equals_the_sample_outputs(ctx):
+    """d_samples / d_valid / d_ray_count are optional: the accumulator alone must see the same sums."""
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame.full(70, 50, 6)
+    a1 = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    a2 = torch.zeros_like(a1)
+    rng1 = rt.Rng(frame)
+    rt.render_distributed(scene, camera, frame, rng1, 4, accum=a1)
+    rng2, _, _, _ = _run_gpu(scene, camera, frame, 4, accum=a2)
+    torch.cuda.synchronize()
+    assert torch.equal(a1.view(torch.int32), a2.view(torch.int32))
+    assert np.array_equal(rng1.download(), rng2.download())
 
 
 def test_stream_continues_across_calls_and_accumulates_in_epoch_order(ctx):

@@ -27,6 +27,7 @@ ap.add_argument("--epochs", type=int, default=8)
 ap.add_argument("--calls", type=int, default=3)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
+ap.add_argument("--split", type=int, default=-1, help="1: chain/shade/unwind kernels, 0: the fused kernel, -1: library default")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
@@ -36,6 +37,8 @@ if a.lib:
     _capi._amd = None
     _orig = _capi._load
     _capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / f"librt_amd_{a.lib}.so")) if name == "librt_amd.so" else _orig(name)
+from homework_18_graphics_raytracer_amd import _capi as _c
+_c.amd_lib().rt_set_distributed_split(a.split)
 world = rt.reference_world()
 cam = rt.reference_camera()
 scene = rt.Scene(world)
@@ -60,7 +63,7 @@ pixels = frame.rows * frame.cols
 samples = pixels * a.epochs * a.calls
 casts = int(cnt.item())
 print(json.dumps({
-    "pass": "distributed", "width": a.width, "height": a.height, "depth": a.depth, "tile_pixels": pixels,
+    "pass": "distributed", "split": a.split, "width": a.width, "height": a.height, "depth": a.depth, "tile_pixels": pixels,
     "epochs_per_call": a.epochs, "calls": a.calls, "ms_per_epoch": round(ms / (a.epochs * a.calls), 4),
     "Msamples_per_s": round(samples / ms / 1e3, 2), "Mrays_per_s": round(casts / ms / 1e3, 2),
     "casts_per_sample": round(casts / samples, 3), "rng_state_GB": round(pixels * 2064 / 1e9, 3),
