@@ -79,13 +79,76 @@ __device__ void isaac_generate(uint32_t *st) {
     st[RNG_B] = b;
 }
 
+/* The same, for the lanes of a wave that run dry at the same moment (a divergent branch: after a few dozen epochs the
+ * pixels' streams are out of step and it is usually ONE lane).  Each of the 256 steps has two loads whose address comes
+ * out of the previous one — ~400 K cycles of L2 latency per refill through HBM-resident state, with the other 63 lanes
+ * waiting.  So mem[] is staged in LDS: up to RNG_LDS_SLOTS lanes at a time copy their 1 KB in (16-byte loads, all in
+ * flight together), run the steps there and copy it back.  Slot-interleaved layout (word i of slot k at i * SLOTS + k):
+ * the lanes' accesses to the same i fall in different banks.  More lanes than 2 * SLOTS at once (the first epochs): the
+ * HBM version, all lanes in parallel. */
+#define RNG_LDS_SLOTS 8u
+__device__ void isaac_generate_staged(uint32_t *st, uint32_t *lds) {
+    const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+    if ((uint32_t)__builtin_popcountll(all) > 2u * RNG_LDS_SLOTS) {
+        isaac_generate(st);
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = (uint32_t)__builtin_popcountll(all & ((1ull << lane) - 1ull));
+    for (uint32_t first = 0u; first < 2u * RNG_LDS_SLOTS; first += RNG_LDS_SLOTS) {
+        if (rank < first || rank >= first + RNG_LDS_SLOTS) continue;
+        uint32_t *m = lds + (rank - first);
+        for (uint32_t i = 0; i < 256u; i += 4u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(st + RNG_MEM + i);
+            m[(i + 0u) * RNG_LDS_SLOTS] = v.x;
+            m[(i + 1u) * RNG_LDS_SLOTS] = v.y;
+            m[(i + 2u) * RNG_LDS_SLOTS] = v.z;
+            m[(i + 3u) * RNG_LDS_SLOTS] = v.w;
+        }
+        const uint32_t cc = st[RNG_C] + 1u;
+        st[RNG_C] = cc;
+        uint32_t a = st[RNG_A], b = st[RNG_B] + cc;
+#define RT_ISAAC_STEP(I, MIX)                                                     \
+    {                                                                             \
+        const uint32_t x = m[(I) * RNG_LDS_SLOTS];                                \
+        a = (a ^ (MIX)) + m[(((I) + 128u) & 255u) * RNG_LDS_SLOTS];               \
+        const uint32_t y = a + b + m[((x >> 2) & 255u) * RNG_LDS_SLOTS];          \
+        m[(I) * RNG_LDS_SLOTS] = y;                                               \
+        b = x + m[((y >> 10) & 255u) * RNG_LDS_SLOTS];                            \
+        st[RNG_RESULTS + 255u - (I)] = b;                                         \
+    }
+        for (uint32_t i = 0; i < 256u; i += 4u) {
+            RT_ISAAC_STEP(i, a << 13)
+            RT_ISAAC_STEP(i + 1u, a >> 6)
+            RT_ISAAC_STEP(i + 2u, a << 2)
+            RT_ISAAC_STEP(i + 3u, a >> 16)
+        }
+#undef RT_ISAAC_STEP
+        st[RNG_A] = a;
+        st[RNG_B] = b;
+        for (uint32_t i = 0; i < 256u; i += 4u) {
+            uint4 v;
+            v.x = m[(i + 0u) * RNG_LDS_SLOTS];
+            v.y = m[(i + 1u) * RNG_LDS_SLOTS];
+            v.z = m[(i + 2u) * RNG_LDS_SLOTS];
+            v.w = m[(i + 3u) * RNG_LDS_SLOTS];
+            *reinterpret_cast<uint4 *>(st + RNG_MEM + i) = v;
+        }
+    }
+}
+
 /* BlockRng over the record; `index` lives in a register while a lane works and is stored back at the end */
 struct Rng {
     uint32_t *st;
     uint32_t index;
+    uint32_t *lds; /* the wave's RNG_LDS_SLOTS x 256 words of staging, or nullptr: refill in place */
 };
+__device__ __forceinline__ void rng_refill(Rng &r) {
+    if (r.lds != nullptr) isaac_generate_staged(r.st, r.lds);
+    else isaac_generate(r.st);
+}
 __device__ __forceinline__ uint32_t next_u32(Rng &r) {
-    if (r.index >= 256u) { isaac_generate(r.st); r.index = 0u; }
+    if (r.index >= 256u) { rng_refill(r); r.index = 0u; }
     return r.st[RNG_RESULTS + r.index++];
 }
 __device__ __forceinline__ unsigned long long next_u64(Rng &r) {
@@ -94,12 +157,12 @@ __device__ __forceinline__ unsigned long long next_u64(Rng &r) {
         r.index += 2u;
         return (y << 32) | x;
     } else if (r.index >= 256u) {
-        isaac_generate(r.st);
+        rng_refill(r);
         r.index = 2u;
         return ((unsigned long long)r.st[RNG_RESULTS + 1] << 32) | r.st[RNG_RESULTS + 0];
     } else {
         const unsigned long long x = r.st[RNG_RESULTS + 255];
-        isaac_generate(r.st);
+        rng_refill(r);
         r.index = 1u;
         return ((unsigned long long)r.st[RNG_RESULTS + 0] << 32) | x;
     }
@@ -208,6 +271,7 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
     Rng rng;
     rng.st = dp.rng_states;
     rng.index = 256u;
+    rng.lds = nullptr;
 
     uint32_t phase = DP_DONE;
     uint32_t epoch = 0u;
@@ -609,9 +673,15 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
     const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
 
+    __shared__ uint32_t rng_stage[RNG_LDS_SLOTS * 256u]; /* one wave per workgroup */
     Rng rng;
     rng.st = dp.rng_states;
     rng.index = 256u;
+#ifdef RT_DIST_NO_STAGE /* A/B */
+    rng.lds = nullptr;
+#else
+    rng.lds = rng_stage;
+#endif
     uint32_t phase = DP_DONE;
     uint32_t epoch = 0u;
     Ray req;

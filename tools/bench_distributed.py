@@ -27,6 +27,7 @@ ap.add_argument("--epochs", type=int, default=8)
 ap.add_argument("--calls", type=int, default=3)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
+ap.add_argument("--burn", type=int, default=0, help="untimed epochs first: the pixels' random streams drift out of step over the first ~100 epochs, which is the state a long run is in")
 ap.add_argument("--split", type=int, default=-1, help="1: chain/shade/unwind kernels, 0: the fused kernel, -1: library default")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
@@ -50,6 +51,8 @@ t_seed = time.perf_counter() - t0
 accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
 rt.render_distributed(scene, cam, frame, rng, 1, accum=accum)  # warm-up (also advances the stream; fine for timing)
+if a.burn:
+    rt.render_distributed(scene, cam, frame, rng, a.burn, accum=accum)
 torch.cuda.synchronize()
 cnt.zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,7 +66,7 @@ pixels = frame.rows * frame.cols
 samples = pixels * a.epochs * a.calls
 casts = int(cnt.item())
 print(json.dumps({
-    "pass": "distributed", "split": a.split, "width": a.width, "height": a.height, "depth": a.depth, "tile_pixels": pixels,
+    "pass": "distributed", "split": a.split, "burn": a.burn, "width": a.width, "height": a.height, "depth": a.depth, "tile_pixels": pixels,
     "epochs_per_call": a.epochs, "calls": a.calls, "ms_per_epoch": round(ms / (a.epochs * a.calls), 4),
     "Msamples_per_s": round(samples / ms / 1e3, 2), "Mrays_per_s": round(casts / ms / 1e3, 2),
     "casts_per_sample": round(casts / samples, 3), "rng_state_GB": round(pixels * 2064 / 1e9, 3),
