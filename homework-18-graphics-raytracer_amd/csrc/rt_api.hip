@@ -660,7 +660,9 @@ int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const
 
 struct rt_rng {
     int device;
-    uint32_t *d_states;
+    uint32_t *d_states; /* RT_RNG_DEVICE_WORDS per pixel */
+    uint32_t *d_list;   /* scratch of the look-ahead pass: 1 + pixels words */
+    uint32_t compute_units;
     uint32_t cols, rows, x0, y0, y_step;
 };
 
@@ -678,9 +680,16 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     r->y0 = frame->y0;
     r->y_step = frame->y_step;
     r->d_states = nullptr;
-    const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_STATE_WORDS * sizeof(uint32_t);
+    r->d_list = nullptr;
+    r->compute_units = 256;
+    const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_DEVICE_WORDS * sizeof(uint32_t);
     hipError_t e = hipGetDevice(&r->device);
+    if (e == hipSuccess) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) == hipSuccess && cus > 0) r->compute_units = (uint32_t)cus;
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_list), ((size_t)r->cols * r->rows + 1u) * sizeof(uint32_t));
     if (e == hipSuccess) {
         rt::KernelFrame kf;
         memset(&kf, 0, sizeof kf);
@@ -690,6 +699,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (r->d_states) (void)hipFree(r->d_states);
+        if (r->d_list) (void)hipFree(r->d_list);
         delete r;
         return fail_hip("rt_rng_create", e);
     }
@@ -700,6 +710,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
 int rt_rng_destroy(rt_rng *rng) {
     if (!rng) return RT_OK;
     hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
+    if (rng->d_list) (void)hipFree(rng->d_list);
     delete rng;
     if (e != hipSuccess) return fail_hip("rt_rng_destroy: hipFree", e);
     return RT_OK;
@@ -707,8 +718,17 @@ int rt_rng_destroy(rt_rng *rng) {
 
 int rt_rng_download(const rt_rng *rng, uint32_t *h_states) {
     if (!rng || !h_states) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_download: null argument");
+    /* the device keeps two banks per pixel (the block in use and the next one, generated ahead); what leaves is the
+     * reference's record: the bank in use + the position */
+    const size_t bytes = (size_t)rng->cols * rng->rows * RT_RNG_STATE_WORDS * sizeof(uint32_t);
+    if (bytes == 0) return RT_OK;
     RT_HIP(hipDeviceSynchronize());
-    RT_HIP(hipMemcpy(h_states, rng->d_states, (size_t)rng->cols * rng->rows * RT_RNG_STATE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t *d_tmp = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp), bytes));
+    hipError_t e = rt::launch_rng_export(rng->d_states, rng->cols * rng->rows, d_tmp, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(h_states, d_tmp, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail_hip("rt_rng_download", e);
     return RT_OK;
 }
 
@@ -741,6 +761,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     }
     const size_t n_pixels = (size_t)kf.cols * kf.rows;
     if (n_pixels == 0 || n_epochs == 0) return RT_OK;
+    bool lookahead = true; /* A/B: RT_AMD_RNG_LOOKAHEAD=0 leaves every IsaacCore::generate to the render kernels */
+    if (const char *v = getenv("RT_AMD_RNG_LOOKAHEAD")) lookahead = !(*v == '0');
     rt_scene *mut = const_cast<rt_scene *>(scene);
     if (split && kf.max_depth <= 254) {
         /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
@@ -787,6 +809,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             dp.epoch0 = e0;
             dp.n_epochs = std::min(batch, n_epochs - e0);
             hipError_t e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+            if (e == hipSuccess && lookahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
             if (e == hipSuccess) e = rt::launch_distributed_split(scene->ks, kf, dp, dist_waves, stream);
             if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
         }
@@ -805,6 +828,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     }
     hipError_t e = hipSuccess;
     if (dp.work_queue) e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess && lookahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
     if (e == hipSuccess) e = rt::launch_distributed(scene->ks, kf, dp, dist_waves, stream);
     if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
     return RT_OK;

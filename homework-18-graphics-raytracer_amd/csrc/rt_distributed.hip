@@ -26,8 +26,21 @@
 
 namespace rt {
 
-/* ---- per-pixel RNG record in HBM: mem[256], a, b, c, results[256], index (the oracle's layout) ---- */
-enum : uint32_t { RNG_MEM = 0u, RNG_A = 256u, RNG_B = 257u, RNG_C = 258u, RNG_RESULTS = 259u, RNG_INDEX = 515u, RNG_WORDS = 516u };
+/* ---- per-pixel RNG record in HBM ----------------------------------------------------------------------------------
+ * Two BANKS of the oracle's layout (mem[256], a, b, c, results[256], one spare word).  Bank `cur` is the generator's
+ * state as the reference has it (IsaacRng: the block in use + the position in it); the other bank, when `prepared`, holds
+ * the state after the NEXT IsaacCore::generate, computed ahead of time by rng_prepare_kernel.  A lane that runs dry then
+ * just switches banks.  Why: generate is 256 steps with two address-dependent loads each — tens of microseconds for one
+ * lane with the 63 others of its wave waiting, and after a few dozen epochs the pixels' streams are out of step, so in
+ * the render kernels it is always ONE lane (measured: a third of the chain kernel's wave time).  In the prepare pass all
+ * the lanes of a wave generate together.  rt_rng_download exports bank `cur` + the position: the oracle's record. */
+enum : uint32_t {
+    RNG_MEM = 0u, RNG_A = 256u, RNG_B = 257u, RNG_C = 258u, RNG_RESULTS = 259u, RNG_SPARE = 515u, RNG_BANK_WORDS = 516u,
+    RNG_INDEX = RNG_SPARE,                      /* bank 0's spare word: position in the current block (256 = used up) */
+    RNG_FLAGS = RNG_BANK_WORDS + RNG_SPARE,     /* bank 1's spare word: bit 0 = cur, bit 1 = prepared */
+    RNG_WORDS = 2u * RNG_BANK_WORDS
+};
+static_assert(RNG_WORDS == RT_RNG_DEVICE_WORDS && RNG_BANK_WORDS == RT_RNG_STATE_WORDS, "rt_kernels.h");
 
 __device__ const double ZIG_X[257] = RT_ZIG_NORM_X;
 __device__ const double ZIG_F[257] = RT_ZIG_NORM_F;
@@ -58,39 +71,64 @@ __device__ void isaac_seed(uint32_t *st, unsigned long long seed) {
     st[RNG_C] = 0u;
     for (uint32_t i = 0; i < 256u; ++i) st[RNG_RESULTS + i] = 0u;
     st[RNG_INDEX] = 256u;
+    st[RNG_FLAGS] = 0u; /* bank 0 is current, nothing prepared */
 }
 
-/* IsaacCore::generate; results stored backwards (read forwards = the reference implementation's order) */
-__device__ void isaac_generate(uint32_t *st) {
-    const uint32_t cc = st[RNG_C] + 1u;
-    st[RNG_C] = cc;
-    uint32_t a = st[RNG_A], b = st[RNG_B] + cc;
+/* IsaacCore::generate from bank `src` into bank `dst` (results stored backwards: read forwards = the reference
+ * implementation's order) */
+__device__ void isaac_generate(const uint32_t *src, uint32_t *dst) {
+    for (uint32_t i = 0; i < 256u; i += 4u) *reinterpret_cast<uint4 *>(dst + RNG_MEM + i) = *reinterpret_cast<const uint4 *>(src + RNG_MEM + i);
+    const uint32_t cc = src[RNG_C] + 1u;
+    dst[RNG_C] = cc;
+    uint32_t a = src[RNG_A], b = src[RNG_B] + cc;
     for (uint32_t i = 0; i < 256u; ++i) {
-        const uint32_t x = st[RNG_MEM + i];
+        const uint32_t x = dst[RNG_MEM + i];
         const uint32_t sel = i & 3u;
         const uint32_t mixv = sel == 0u ? (a ^ (a << 13)) : sel == 1u ? (a ^ (a >> 6)) : sel == 2u ? (a ^ (a << 2)) : (a ^ (a >> 16));
-        a = mixv + st[RNG_MEM + ((i + 128u) & 255u)];
-        const uint32_t y = a + b + st[RNG_MEM + ((x >> 2) & 255u)];
-        st[RNG_MEM + i] = y;
-        b = x + st[RNG_MEM + ((y >> 10) & 255u)];
-        st[RNG_RESULTS + 255u - i] = b;
+        a = mixv + dst[RNG_MEM + ((i + 128u) & 255u)];
+        const uint32_t y = a + b + dst[RNG_MEM + ((x >> 2) & 255u)];
+        dst[RNG_MEM + i] = y;
+        b = x + dst[RNG_MEM + ((y >> 10) & 255u)];
+        dst[RNG_RESULTS + 255u - i] = b;
     }
-    st[RNG_A] = a;
-    st[RNG_B] = b;
+    dst[RNG_A] = a;
+    dst[RNG_B] = b;
 }
 
-/* The same, for the lanes of a wave that run dry at the same moment (a divergent branch: after a few dozen epochs the
- * pixels' streams are out of step and it is usually ONE lane).  Each of the 256 steps has two loads whose address comes
- * out of the previous one — ~400 K cycles of L2 latency per refill through HBM-resident state, with the other 63 lanes
- * waiting.  So mem[] is staged in LDS: up to RNG_LDS_SLOTS lanes at a time copy their 1 KB in (16-byte loads, all in
- * flight together), run the steps there and copy it back.  Slot-interleaved layout (word i of slot k at i * SLOTS + k):
- * the lanes' accesses to the same i fall in different banks.  More lanes than 2 * SLOTS at once (the first epochs): the
- * HBM version, all lanes in parallel. */
+/* The steps of generate on a mem[] staged in LDS, slot-interleaved (word i of slot k at i * SLOTS + k: the lanes'
+ * accesses to the same i fall in different banks); results go straight to `dst`. */
 #define RNG_LDS_SLOTS 8u
-__device__ void isaac_generate_staged(uint32_t *st, uint32_t *lds) {
+__device__ __forceinline__ void isaac_steps_lds(uint32_t *m, const uint32_t *src, uint32_t *dst) {
+    const uint32_t cc = src[RNG_C] + 1u;
+    dst[RNG_C] = cc;
+    uint32_t a = src[RNG_A], b = src[RNG_B] + cc;
+#define RT_ISAAC_STEP(I, MIX)                                                     \
+    {                                                                             \
+        const uint32_t x = m[(I) * RNG_LDS_SLOTS];                                \
+        a = (a ^ (MIX)) + m[(((I) + 128u) & 255u) * RNG_LDS_SLOTS];               \
+        const uint32_t y = a + b + m[((x >> 2) & 255u) * RNG_LDS_SLOTS];          \
+        m[(I) * RNG_LDS_SLOTS] = y;                                               \
+        b = x + m[((y >> 10) & 255u) * RNG_LDS_SLOTS];                            \
+        dst[RNG_RESULTS + 255u - (I)] = b;                                        \
+    }
+    for (uint32_t i = 0; i < 256u; i += 4u) {
+        RT_ISAAC_STEP(i, a << 13)
+        RT_ISAAC_STEP(i + 1u, a >> 6)
+        RT_ISAAC_STEP(i + 2u, a << 2)
+        RT_ISAAC_STEP(i + 3u, a >> 16)
+    }
+#undef RT_ISAAC_STEP
+    dst[RNG_A] = a;
+    dst[RNG_B] = b;
+}
+
+/* generate for the lanes of a render wave that run dry WITHOUT a prepared bank (a pixel that used more than a whole
+ * block within one visit — rare): a divergent branch, usually one lane.  mem[] goes through LDS, up to RNG_LDS_SLOTS
+ * lanes at a time; more than 2 * SLOTS lanes at once take the HBM version, all in parallel. */
+__device__ void isaac_generate_staged(const uint32_t *src, uint32_t *dst, uint32_t *lds) {
     const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
-    if ((uint32_t)__builtin_popcountll(all) > 2u * RNG_LDS_SLOTS) {
-        isaac_generate(st);
+    if (lds == nullptr || (uint32_t)__builtin_popcountll(all) > 2u * RNG_LDS_SLOTS) {
+        isaac_generate(src, dst);
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -99,53 +137,48 @@ __device__ void isaac_generate_staged(uint32_t *st, uint32_t *lds) {
         if (rank < first || rank >= first + RNG_LDS_SLOTS) continue;
         uint32_t *m = lds + (rank - first);
         for (uint32_t i = 0; i < 256u; i += 4u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(st + RNG_MEM + i);
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + RNG_MEM + i);
             m[(i + 0u) * RNG_LDS_SLOTS] = v.x;
             m[(i + 1u) * RNG_LDS_SLOTS] = v.y;
             m[(i + 2u) * RNG_LDS_SLOTS] = v.z;
             m[(i + 3u) * RNG_LDS_SLOTS] = v.w;
         }
-        const uint32_t cc = st[RNG_C] + 1u;
-        st[RNG_C] = cc;
-        uint32_t a = st[RNG_A], b = st[RNG_B] + cc;
-#define RT_ISAAC_STEP(I, MIX)                                                     \
-    {                                                                             \
-        const uint32_t x = m[(I) * RNG_LDS_SLOTS];                                \
-        a = (a ^ (MIX)) + m[(((I) + 128u) & 255u) * RNG_LDS_SLOTS];               \
-        const uint32_t y = a + b + m[((x >> 2) & 255u) * RNG_LDS_SLOTS];          \
-        m[(I) * RNG_LDS_SLOTS] = y;                                               \
-        b = x + m[((y >> 10) & 255u) * RNG_LDS_SLOTS];                            \
-        st[RNG_RESULTS + 255u - (I)] = b;                                         \
-    }
-        for (uint32_t i = 0; i < 256u; i += 4u) {
-            RT_ISAAC_STEP(i, a << 13)
-            RT_ISAAC_STEP(i + 1u, a >> 6)
-            RT_ISAAC_STEP(i + 2u, a << 2)
-            RT_ISAAC_STEP(i + 3u, a >> 16)
-        }
-#undef RT_ISAAC_STEP
-        st[RNG_A] = a;
-        st[RNG_B] = b;
+        isaac_steps_lds(m, src, dst);
         for (uint32_t i = 0; i < 256u; i += 4u) {
             uint4 v;
             v.x = m[(i + 0u) * RNG_LDS_SLOTS];
             v.y = m[(i + 1u) * RNG_LDS_SLOTS];
             v.z = m[(i + 2u) * RNG_LDS_SLOTS];
             v.w = m[(i + 3u) * RNG_LDS_SLOTS];
-            *reinterpret_cast<uint4 *>(st + RNG_MEM + i) = v;
+            *reinterpret_cast<uint4 *>(dst + RNG_MEM + i) = v;
         }
     }
 }
 
-/* BlockRng over the record; `index` lives in a register while a lane works and is stored back at the end */
+/* BlockRng over the record; position and flags live in registers while a lane works on the pixel */
 struct Rng {
-    uint32_t *st;
+    uint32_t *rec;  /* the pixel's record */
+    uint32_t *st;   /* its current bank */
     uint32_t index;
-    uint32_t *lds; /* the wave's RNG_LDS_SLOTS x 256 words of staging, or nullptr: refill in place */
+    uint32_t flags; /* bit 0 = cur, bit 1 = prepared */
+    uint32_t *lds;  /* the wave's RNG_LDS_SLOTS x 256 words of staging, or nullptr */
 };
+__device__ __forceinline__ void rng_open(Rng &r, uint32_t *rec) {
+    r.rec = rec;
+    r.index = rec[RNG_INDEX];
+    r.flags = rec[RNG_FLAGS];
+    r.st = rec + (r.flags & 1u) * RNG_BANK_WORDS;
+}
+__device__ __forceinline__ void rng_park(Rng &r) {
+    r.rec[RNG_INDEX] = r.index;
+    r.rec[RNG_FLAGS] = r.flags;
+}
+/* the current block is used up: move on to the next one (IsaacCore::generate, BlockRng::generate_and_set) */
 __device__ __forceinline__ void rng_refill(Rng &r) {
-    if (r.lds != nullptr) isaac_generate_staged(r.st, r.lds);
-    else isaac_generate(r.st);
+    uint32_t *other = r.rec + ((r.flags & 1u) ^ 1u) * RNG_BANK_WORDS;
+    if ((r.flags & 2u) == 0u) isaac_generate_staged(r.st, other, r.lds);
+    r.st = other;
+    r.flags = (r.flags & 1u) ^ 1u;
 }
 __device__ __forceinline__ uint32_t next_u32(Rng &r) {
     if (r.index >= 256u) { rng_refill(r); r.index = 0u; }
@@ -220,6 +253,96 @@ hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t 
     return hipGetLastError();
 }
 
+/* ---- the look-ahead pass: every pixel gets its next block before a render kernel may need it ---- */
+
+/* list[1 + k] = the pixels without a prepared bank; list[0] = how many (zeroed by the launcher) */
+__global__ __launch_bounds__(256) void rng_scan_kernel(const uint32_t *states, uint32_t n_pixels, uint32_t *list) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = p < n_pixels && (states[(size_t)p * RNG_WORDS + RNG_FLAGS] & 2u) == 0u;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0u;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(list, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+    if (want) list[1u + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = p;
+}
+
+/* One wave per workgroup, RNG_LDS_SLOTS records at a time: all 64 lanes copy the mem[] of the 8 records into LDS (8 lanes
+ * x 128 B each), lanes 0-7 run the steps — one record each, side by side — and all lanes copy the new mem[] out into the
+ * other bank.  The steps are latency (two dependent LDS reads each); the chip-wide rate comes from the number of
+ * records in flight, which LDS bounds at 160 per CU. */
+__global__ __launch_bounds__(64) void rng_prepare_kernel(uint32_t *states, const uint32_t *list) {
+    __shared__ uint32_t stage[RNG_LDS_SLOTS * 256u];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = list[0];
+    const uint32_t k = lane >> 3, part = lane & 7u; /* copy role: record k, words [32 part, 32 part + 32) */
+    for (uint32_t first = blockIdx.x * RNG_LDS_SLOTS; first < count; first += gridDim.x * RNG_LDS_SLOTS) {
+        uint32_t *rec = nullptr, *src = nullptr, *dst = nullptr;
+        if (first + k < count) {
+            rec = states + (size_t)list[1u + first + k] * RNG_WORDS;
+            const uint32_t cur = rec[RNG_FLAGS] & 1u;
+            src = rec + cur * RNG_BANK_WORDS;
+            dst = rec + (cur ^ 1u) * RNG_BANK_WORDS;
+            for (uint32_t i = part * 32u; i < part * 32u + 32u; i += 4u) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + RNG_MEM + i);
+                stage[(i + 0u) * RNG_LDS_SLOTS + k] = v.x;
+                stage[(i + 1u) * RNG_LDS_SLOTS + k] = v.y;
+                stage[(i + 2u) * RNG_LDS_SLOTS + k] = v.z;
+                stage[(i + 3u) * RNG_LDS_SLOTS + k] = v.w;
+            }
+        }
+        __syncthreads();
+        if (lane < RNG_LDS_SLOTS && first + lane < count) {
+            uint32_t *r = states + (size_t)list[1u + first + lane] * RNG_WORDS;
+            const uint32_t cur = r[RNG_FLAGS] & 1u;
+            isaac_steps_lds(stage + lane, r + cur * RNG_BANK_WORDS, r + (cur ^ 1u) * RNG_BANK_WORDS);
+            r[RNG_FLAGS] = cur | 2u;
+        }
+        __syncthreads();
+        if (rec != nullptr) {
+            for (uint32_t i = part * 32u; i < part * 32u + 32u; i += 4u) {
+                uint4 v;
+                v.x = stage[(i + 0u) * RNG_LDS_SLOTS + k];
+                v.y = stage[(i + 1u) * RNG_LDS_SLOTS + k];
+                v.z = stage[(i + 2u) * RNG_LDS_SLOTS + k];
+                v.w = stage[(i + 3u) * RNG_LDS_SLOTS + k];
+                *reinterpret_cast<uint4 *>(dst + RNG_MEM + i) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_rng_prepare(uint32_t *states, uint32_t n_pixels, uint32_t *list, uint32_t compute_units, hipStream_t stream) {
+    if (n_pixels == 0u) return hipSuccess;
+    hipError_t e = hipMemsetAsync(list, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rng_scan_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, states, n_pixels, list);
+    uint32_t groups = (n_pixels + RNG_LDS_SLOTS - 1u) / RNG_LDS_SLOTS;
+    const uint32_t resident = compute_units * 20u; /* 8 KB of LDS each */
+    if (groups > resident) groups = resident;
+    hipLaunchKernelGGL(rng_prepare_kernel, dim3(groups), dim3(64), 0, stream, states, list);
+    return hipGetLastError();
+}
+
+/* the oracle's record of every pixel: bank `cur` + the position (rt_rng_download) */
+__global__ __launch_bounds__(256) void rng_export_kernel(const uint32_t *states, uint32_t n_pixels, uint32_t *out) {
+    const size_t n_words = (size_t)n_pixels * RNG_BANK_WORDS;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = w / RNG_BANK_WORDS;
+        const uint32_t i = (uint32_t)(w - p * RNG_BANK_WORDS);
+        const uint32_t *rec = states + p * RNG_WORDS;
+        out[w] = i == RNG_SPARE ? rec[RNG_INDEX] : rec[(rec[RNG_FLAGS] & 1u) * RNG_BANK_WORDS + i];
+    }
+}
+
+hipError_t launch_rng_export(const uint32_t *states, uint32_t n_pixels, uint32_t *out, hipStream_t stream) {
+    if (n_pixels == 0u) return hipSuccess;
+    hipLaunchKernelGGL(rng_export_kernel, dim3(4096), dim3(256), 0, stream, states, n_pixels, out);
+    return hipGetLastError();
+}
+
 /* ---- the kernel ------------------------------------------------------------------------------- */
 
 enum : uint32_t {
@@ -269,8 +392,9 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
     const size_t n_pixels = total_slots;
 
     Rng rng;
-    rng.st = dp.rng_states;
+    rng.rec = rng.st = dp.rng_states;
     rng.index = 256u;
+    rng.flags = 0u;
     rng.lds = nullptr;
 
     uint32_t phase = DP_DONE;
@@ -343,8 +467,7 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
                 const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
                 clip_y = (fr.half_height - (float)y) / fr.height_f; /* main.rs:1134-1135 */
                 clip_x = ((float)x - fr.half_width) / fr.height_f;
-                rng.st = dp.rng_states + (size_t)out_index * RNG_WORDS;
-                rng.index = rng.st[RNG_INDEX];
+                rng_open(rng, dp.rng_states + (size_t)out_index * RNG_WORDS);
                 accum = v3(0.0f, 0.0f, 0.0f);
                 if (dp.accum != nullptr) accum = v3(dp.accum[(size_t)out_index * 3u], dp.accum[(size_t)out_index * 3u + 1u], dp.accum[(size_t)out_index * 3u + 2u]);
                 epoch = 0u;
@@ -599,7 +722,7 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
                 if (epoch < dp.n_epochs) {
                     start_epoch();
                 } else { /* this pixel is finished for this call: park its stream position and its sum */
-                    rng.st[RNG_INDEX] = rng.index;
+                    rng_park(rng);
                     if (dp.accum != nullptr) {
                         float *o = dp.accum + (size_t)out_index * 3u;
                         o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
@@ -675,8 +798,9 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 
     __shared__ uint32_t rng_stage[RNG_LDS_SLOTS * 256u]; /* one wave per workgroup */
     Rng rng;
-    rng.st = dp.rng_states;
+    rng.rec = rng.st = dp.rng_states;
     rng.index = 256u;
+    rng.flags = 0u;
 #ifdef RT_DIST_NO_STAGE /* A/B */
     rng.lds = nullptr;
 #else
@@ -750,8 +874,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
                 clip_y = (fr.half_height - (float)y) / fr.height_f;
                 clip_x = ((float)x - fr.half_width) / fr.height_f;
-                rng.st = dp.rng_states + (size_t)out_index * RNG_WORDS;
-                rng.index = rng.st[RNG_INDEX];
+                rng_open(rng, dp.rng_states + (size_t)out_index * RNG_WORDS);
                 epoch = 0u;
                 start_epoch();
             }
@@ -906,7 +1029,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
             if (epoch < dp.n_epochs) {
                 start_epoch();
             } else {
-                rng.st[RNG_INDEX] = rng.index; /* park the stream position */
+                rng_park(rng); /* the stream position */
                 phase = DP_DONE;
             }
         }

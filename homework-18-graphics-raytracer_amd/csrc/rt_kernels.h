@@ -117,7 +117,7 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigne
 
 /* distributed pass (rt_distributed.hip) */
 struct DistParams {
-    uint32_t *rng_states;          /* RT_RNG_STATE_WORDS u32 per tile pixel */
+    uint32_t *rng_states;          /* RT_RNG_DEVICE_WORDS u32 per tile pixel */
     uint32_t n_epochs;
     float focus, blur;             /* main.rs:1147-1148 */
     float *accum;                  /* pixels*3, += every surviving sample; may be null */
@@ -135,8 +135,12 @@ struct DistParams {
     uint32_t sp_slots;             /* max_depth + 1 */
 };
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
-#define RT_RNG_STATE_WORDS 516u
+#define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
+#define RT_RNG_DEVICE_WORDS 1032u /* the device record: two banks of it (rt_distributed.hip) */
 hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t stream);
+/* look-ahead: generate the next block of every pixel that has none prepared; list = n_pixels + 1 words of scratch */
+hipError_t launch_rng_prepare(uint32_t *states, uint32_t n_pixels, uint32_t *list, uint32_t compute_units, hipStream_t stream);
+hipError_t launch_rng_export(const uint32_t *states, uint32_t n_pixels, uint32_t *out, hipStream_t stream);
 hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
 hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
 

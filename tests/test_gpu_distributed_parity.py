@@ -84,6 +84,31 @@ def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs):
     assert np.array_equal(accum.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("lookahead", ["1", "0"])
+@pytest.mark.parametrize("calls", [(70,), (9, 1, 30, 30), (1,) * 12 + (58,)])
+def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
+    """~10 words per sample: 70 epochs use two to three 256-word blocks per pixel.  The device keeps the next block
+    prepared ahead of time (look-ahead pass before every batch); a pixel that needs a second block within one visit
+    generates it in the render kernel.  Every mix of the two must leave the reference's stream and the reference's record."""
+    world, camera, scene = ctx
+    frame = rt.Frame.full(24, 17, 8)
+    os.environ["RT_AMD_RNG_LOOKAHEAD"] = lookahead
+    try:
+        rng, got, flags, casts = None, [], [], 0
+        for n in calls:
+            rng, s, v, c = _run_gpu(scene, camera, frame, n, rng=rng)
+            got.append(s)
+            flags.append(v)
+            casts += c
+    finally:
+        del os.environ["RT_AMD_RNG_LOOKAHEAD"]
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, sum(calls))
+    assert np.array_equal(np.concatenate(got).view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(np.concatenate(flags), wv) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
 def test_accumulate_only_call_equals_the_sample_outputs(ctx):
     """d_samples / d_valid / d_ray_count are optional: the accumulator alone must see the same sums."""
     import torch
