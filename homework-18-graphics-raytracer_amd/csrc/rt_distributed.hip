@@ -351,7 +351,8 @@ enum : uint32_t {
     DP_NEXT = 2u,        /* cast of the reflected / escape ray of a level      (main.rs:564, 583, 603) */
     DP_SHADOW = 3u,      /* a shadow ray of get_shade                          (main.rs:435) */
     DP_REFR_INSIDE = 4u, /* get_refract's first inside cast                    (main.rs:371) */
-    DP_REFR_BOUNCE = 5u  /* a total-internal-reflection bounce                 (main.rs:381) */
+    DP_REFR_BOUNCE = 5u, /* a total-internal-reflection bounce                 (main.rs:381) */
+    DP_START = 6u        /* chain kernel: the next epoch's shoot_focus is due */
 };
 
 struct DFrame {
@@ -876,13 +877,16 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 clip_x = ((float)x - fr.half_width) / fr.height_f;
                 rng_open(rng, dp.rng_states + (size_t)out_index * RNG_WORDS);
                 epoch = 0u;
-                start_epoch();
+                phase = DP_START;
             }
             const uint32_t n_need = (uint32_t)__builtin_popcountll(need);
             q_next += n_need < avail ? n_need : avail;
             need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
         }
         if (__builtin_amdgcn_ballot_w64(phase != DP_DONE) == 0ull) break;
+        /* one copy of each expensive piece per iteration — the lanes of a wave are in all phases at once, so whatever
+         * appears in several branches is executed several times over */
+        if (phase == DP_START) start_epoch();
 
         CastResult cr;
         cr.prim = -1;
@@ -898,12 +902,13 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         enum { GO_LEVEL, GO_TRY_EXIT, GO_END } go = GO_END;
         bool terminal = false; /* the sample's value is a get_shade (request slot sp); else black */
         HitGeom ih = h;
+        if (cr.prim >= 0) ih = finish_hit(sc, req, cr, false); /* the hit just found */
         V3 i_in_dir = req.d;
         uint32_t i_in_mode = req.mode;
 
         if (phase == DP_PRIMARY) {
             if (cr.prim >= 0) { /* a miss: black (main.rs:1154) */
-                h = finish_hit(sc, req, cr, false);
+                h = ih;
                 h_in_dir = req.d;
                 h_in_mode = req.mode;
                 go = GO_LEVEL;
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                     factor = kind == 0u ? get_diffuse(m, h.normal, req.d) : get_specular(m, h.normal, view, req.d);
                 }
                 dp.sp_frame[(size_t)sp * n_samples + (size_t)epoch * n_pixels + out_index] = make_float4(factor.x, factor.y, factor.z, duf(kind));
-                h = finish_hit(sc, req, cr, false);
+                h = ih;
                 h_in_dir = req.d;
                 h_in_mode = req.mode;
                 emit_request(req.d); /* get_shade(&next_hit) (main.rs:565, 584, 604): frame sp's shade */
@@ -934,9 +939,6 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
             }
         } else { /* DP_REFR_INSIDE / DP_REFR_BOUNCE; a miss is Refraction::Infinite -> black (main.rs:610) */
             if (cr.prim >= 0) {
-                ih = finish_hit(sc, req, cr, false);
-                i_in_dir = req.d;
-                i_in_mode = req.mode;
                 if (phase == DP_REFR_INSIDE) {
                     travel = distance(ih.pos, h.pos);
                     retry = 0;
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
             dp.sp_hdr[(size_t)epoch * n_pixels + out_index] = (uint32_t)sp | (terminal ? 0x100u : 0u);
             epoch += 1u;
             if (epoch < dp.n_epochs) {
-                start_epoch();
+                phase = DP_START;
             } else {
                 rng_park(rng); /* the stream position */
                 phase = DP_DONE;
@@ -1042,24 +1044,39 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     }
 }
 
-/* get_shade (main.rs:407-464) for request slot blockIdx.y of 64 consecutive samples per wave */
-__global__ __launch_bounds__(64, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples) {
+/* get_shade (main.rs:407-464) for every request of the batch.  The request arrays are sparse — slot k of a sample is in
+ * use only if its chain got that far (90 % at slot 0, a few per cent at slot 8) — so a workgroup first lists the live
+ * (slot, sample) pairs of its `tile` samples in LDS and its waves then work through the list 64 at a time with
+ * every lane busy.  No global atomics; the order within the list does not matter (each result has its own address). */
+__global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile) {
+    extern __shared__ uint32_t shade_list[]; /* [0] count, then slot << 24 | sample - tile0 */
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.y;
-    uint32_t casts = 0u;
-    for (size_t first = (size_t)blockIdx.x * 64u; first < n_samples; first += (size_t)gridDim.x * 64u) {
-        const size_t s = first + lane;
-        bool active = false;
-        if (s < n_samples) {
-            const uint32_t hdr = dp.sp_hdr[s];
-            active = slot < (hdr & 0xffu) + ((hdr >> 8) & 1u);
+    const size_t tile0 = (size_t)blockIdx.x * tile;
+    if (threadIdx.x == 0u) shade_list[0] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
+        if (tile0 + i < n_samples) {
+            const uint32_t hdr = dp.sp_hdr[tile0 + i];
+            const uint32_t cnt = (hdr & 0xffu) + ((hdr >> 8) & 1u);
+            if (cnt != 0u) {
+                const uint32_t base = atomicAdd(&shade_list[0], cnt);
+                for (uint32_t k = 0; k < cnt; ++k) shade_list[1u + base + k] = (k << 24) | i;
+            }
         }
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+    }
+    __syncthreads();
+    const uint32_t total = shade_list[0];
+    uint32_t casts = 0u;
+    for (uint32_t first = (threadIdx.x >> 6) * 64u; first < total; first += blockDim.x) {
+        const bool active = first + lane < total;
         V3 pos = v3(0.0f, 0.0f, 0.0f), normal = v3(0.0f, 0.0f, 1.0f), view = v3(0.0f, 0.0f, 1.0f);
         float u = 0.0f, v = 0.0f;
         uint32_t obj = 0u, prim = 0u;
+        size_t at = 0;
         if (active) {
-            const uint4 *r = dp.sp_req + ((size_t)slot * n_samples + s) * 4u;
+            const uint32_t e = shade_list[1u + first + lane];
+            at = (size_t)(e >> 24) * n_samples + tile0 + (e & 0xffffffu);
+            const uint4 *r = dp.sp_req + at * 4u;
             const uint4 a = r[0], b = r[1], c = r[2], d = r[3];
             pos = v3(duf(a.x), duf(a.y), duf(a.z)); u = duf(a.w);
             normal = v3(duf(b.x), duf(b.y), duf(b.z)); v = duf(b.w);
@@ -1105,7 +1122,7 @@ __global__ __launch_bounds__(64, 6) void dist_shade_kernel(const KernelScene sc,
                 }
             }
         }
-        if (active) dp.sp_shade[(size_t)slot * n_samples + s] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        if (active) dp.sp_shade[at] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     }
     if (dp.ray_count != nullptr) {
         for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
@@ -1172,9 +1189,11 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
     hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     const size_t n_samples = (size_t)total * dp.n_epochs;
     const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
-    size_t shade_waves = (n_samples + 63u) / 64u;
-    if (shade_waves > 65536u) shade_waves = 65536u;
-    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_waves, slots), dim3(64), 0, stream, sc, dp, n_samples);
+    uint32_t tile = 512u; /* samples per workgroup: the list of their live requests must fit 48 KB of LDS */
+    while (tile > 32u && (1u + (size_t)tile * slots) * sizeof(uint32_t) > 49152u) tile >>= 1;
+    const size_t shade_tiles = (n_samples + tile - 1u) / tile;
+    const size_t shade_lds = (1u + (size_t)tile * slots) * sizeof(uint32_t); /* 18 KB at depth 8 */
+    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_tiles), dim3(256), shade_lds, stream, sc, dp, n_samples, tile);
     size_t blocks = ((size_t)total + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
     hipLaunchKernelGGL(dist_unwind_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp, (size_t)total, (size_t)total);
