@@ -193,8 +193,10 @@ int rt_render_whitted_host(const rt_scene *scene, const rt_camera *camera, const
  * Replaces the par_iter_mut closure at src/main.rs:1131-1156 and the per-pixel RNG construction at
  * main.rs:1117-1127.  rt_rng is the device-resident array of per-pixel IsaacRng states of one tile
  * (rand 0.5 IsaacRng::new_from_u64(y * 2^33 + x); 516 u32 per pixel: mem[256], a, b, c, results[256],
- * index).  It is mutable and exclusive to one render call at a time (the reference hands each pixel
- * `&mut` access, main.rs:1131); the random stream continues from call to call. */
+ * index — that is what rt_rng_download returns; on the device a pixel has two such banks, the block in use and the
+ * next one, which a look-ahead pass generates before the render kernels can need it: 4128 B per pixel).  It is mutable
+ * and exclusive to one render call at a time (the reference hands each pixel `&mut` access, main.rs:1131); the random
+ * stream continues from call to call. */
 typedef struct rt_rng rt_rng;
 
 int rt_rng_state_words(void);
