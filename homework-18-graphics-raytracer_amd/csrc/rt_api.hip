@@ -663,6 +663,12 @@ struct rt_rng {
     uint32_t *d_states; /* RT_RNG_DEVICE_WORDS per pixel */
     uint32_t *d_list;   /* scratch of the look-ahead pass: 1 + pixels words */
     uint32_t compute_units;
+    /* The look-ahead for the NEXT batch runs on a stream of its own next to this batch's shade kernel (nothing after
+     * the chain kernel touches the records).  ahead = every pixel has its next block, as of the work enqueued so far. */
+    hipStream_t aux;
+    hipEvent_t ev_chain, ev_prepared;
+    bool ahead;
+    hipStream_t main_stream; /* of the call in progress (for the after-chain hook) */
     uint32_t cols, rows, x0, y0, y_step;
 };
 
@@ -682,6 +688,10 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     r->d_states = nullptr;
     r->d_list = nullptr;
     r->compute_units = 256;
+    r->aux = nullptr;
+    r->ev_chain = r->ev_prepared = nullptr;
+    r->ahead = false;
+    r->main_stream = nullptr;
     const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_DEVICE_WORDS * sizeof(uint32_t);
     hipError_t e = hipGetDevice(&r->device);
     if (e == hipSuccess) {
@@ -690,6 +700,9 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_list), ((size_t)r->cols * r->rows + 1u) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_chain, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_prepared, hipEventDisableTiming);
     if (e == hipSuccess) {
         rt::KernelFrame kf;
         memset(&kf, 0, sizeof kf);
@@ -700,6 +713,9 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (e != hipSuccess) {
         if (r->d_states) (void)hipFree(r->d_states);
         if (r->d_list) (void)hipFree(r->d_list);
+        if (r->ev_chain) (void)hipEventDestroy(r->ev_chain);
+        if (r->ev_prepared) (void)hipEventDestroy(r->ev_prepared);
+        if (r->aux) (void)hipStreamDestroy(r->aux);
         delete r;
         return fail_hip("rt_rng_create", e);
     }
@@ -710,7 +726,11 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
 int rt_rng_destroy(rt_rng *rng) {
     if (!rng) return RT_OK;
     hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
+    if (rng->aux) (void)hipStreamSynchronize(rng->aux);
     if (rng->d_list) (void)hipFree(rng->d_list);
+    if (rng->ev_chain) (void)hipEventDestroy(rng->ev_chain);
+    if (rng->ev_prepared) (void)hipEventDestroy(rng->ev_prepared);
+    if (rng->aux) (void)hipStreamDestroy(rng->aux);
     delete rng;
     if (e != hipSuccess) return fail_hip("rt_rng_destroy: hipFree", e);
     return RT_OK;
@@ -730,6 +750,17 @@ int rt_rng_download(const rt_rng *rng, uint32_t *h_states) {
     (void)hipFree(d_tmp);
     if (e != hipSuccess) return fail_hip("rt_rng_download", e);
     return RT_OK;
+}
+
+/* after the chain kernel of a batch: look-ahead for the next batch on the aux stream */
+static hipError_t lookahead_after_chain(void *ctx) {
+    rt_rng *rng = static_cast<rt_rng *>(ctx);
+    hipError_t e = hipEventRecord(rng->ev_chain, rng->main_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(rng->aux, rng->ev_chain, 0);
+    if (e == hipSuccess) e = rt::launch_rng_prepare(rng->d_states, rng->cols * rng->rows, rng->d_list, rng->compute_units, rng->aux);
+    if (e == hipSuccess) e = hipEventRecord(rng->ev_prepared, rng->aux);
+    if (e == hipSuccess) rng->ahead = true;
+    return e;
 }
 
 int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
@@ -763,6 +794,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     if (n_pixels == 0 || n_epochs == 0) return RT_OK;
     bool lookahead = true; /* A/B: RT_AMD_RNG_LOOKAHEAD=0 leaves every IsaacCore::generate to the render kernels */
     if (const char *v = getenv("RT_AMD_RNG_LOOKAHEAD")) lookahead = !(*v == '0');
+    bool overlap = true; /* A/B: RT_AMD_RNG_OVERLAP=0 runs the look-ahead in line, before each chain kernel */
+    if (const char *v = getenv("RT_AMD_RNG_OVERLAP")) overlap = !(*v == '0');
     rt_scene *mut = const_cast<rt_scene *>(scene);
     if (split && kf.max_depth <= 254) {
         /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
@@ -809,8 +842,12 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             dp.epoch0 = e0;
             dp.n_epochs = std::min(batch, n_epochs - e0);
             hipError_t e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
-            if (e == hipSuccess && lookahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
-            if (e == hipSuccess) e = rt::launch_distributed_split(scene->ks, kf, dp, dist_waves, stream);
+            if (e == hipSuccess && lookahead && !rng->ahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
+            rng->ahead = false; /* the chain kernel uses blocks up */
+            rng->main_stream = stream;
+            if (e == hipSuccess) e = rt::launch_distributed_split(scene->ks, kf, dp, dist_waves, stream, lookahead && overlap ? lookahead_after_chain : nullptr, rng);
+            /* the next chain kernel — of this call or, on whatever stream is ordered after this one, of the next — needs the prepared blocks */
+            if (e == hipSuccess && rng->ahead) e = hipStreamWaitEvent(stream, rng->ev_prepared, 0);
             if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
         }
         return RT_OK;
@@ -828,7 +865,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     }
     hipError_t e = hipSuccess;
     if (dp.work_queue) e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
-    if (e == hipSuccess && lookahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
+    if (e == hipSuccess && lookahead && !rng->ahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
+    rng->ahead = false;
     if (e == hipSuccess) e = rt::launch_distributed(scene->ks, kf, dp, dist_waves, stream);
     if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
     return RT_OK;

@@ -1180,13 +1180,18 @@ size_t distributed_split_bytes_per_sample(int32_t max_depth) {
 }
 
 /* one batch of dp.n_epochs epochs (dp.epoch0 = its first epoch within the call); dp.work_queue zeroed */
-hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
+hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream,
+                                    DistAfterChain after_chain, void *after_chain_ctx) {
     const uint32_t total = fr.cols * fr.rows;
     if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
     uint32_t waves = (total + 63u) / 64u;
     const uint32_t chain_waves = resident_waves / 3u * (uint32_t)RT_DIST_CHAIN_MIN_WAVES; /* resident_waves is sized for 3 per SIMD */
     if (waves > chain_waves) waves = chain_waves;
     hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    if (after_chain != nullptr) {
+        const hipError_t e = after_chain(after_chain_ctx);
+        if (e != hipSuccess) return e;
+    }
     const size_t n_samples = (size_t)total * dp.n_epochs;
     const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
     uint32_t tile = 512u; /* samples per workgroup: the list of their live requests must fit 48 KB of LDS */
