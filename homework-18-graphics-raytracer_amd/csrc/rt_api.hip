@@ -799,14 +799,15 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     rt_scene *mut = const_cast<rt_scene *>(scene);
     if (split && kf.max_depth <= 254) {
         /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
-         * many epochs as fit the workspace cap (RT_AMD_DIST_WS_MB, default 8 GiB; one epoch at least) */
-        size_t cap = (size_t)8192 << 20;
+         * many epochs as fit the workspace cap (RT_AMD_DIST_WS_MB, default 16 GiB; one epoch at least) and never more than 16 — a
+         * visit of a pixel should not need more random words than the block in use plus the one prepared ahead */
+        size_t cap = (size_t)16384 << 20;
         if (const char *v = getenv("RT_AMD_DIST_WS_MB")) {
             if (*v) cap = (size_t)strtoull(v, nullptr, 10) << 20;
         }
         const uint32_t slots = (uint32_t)(kf.max_depth > 0 ? kf.max_depth : 0) + 1u;
         const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
-        uint32_t batch = (uint32_t)std::min<size_t>(n_epochs, std::max<size_t>(1, cap / per_epoch));
+        uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
         auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
         const size_t n_samples = n_pixels * batch;
         size_t off = 0;

@@ -20,6 +20,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rt_cast.h"
 #include "rt_ziggurat_tables.h"
@@ -1185,7 +1186,11 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
     const uint32_t total = fr.cols * fr.rows;
     if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
     uint32_t waves = (total + 63u) / 64u;
-    const uint32_t chain_waves = resident_waves / 3u * (uint32_t)RT_DIST_CHAIN_MIN_WAVES; /* resident_waves is sized for 3 per SIMD */
+    uint32_t chain_waves = resident_waves / 3u * (uint32_t)RT_DIST_CHAIN_MIN_WAVES; /* resident_waves is sized for 3 per SIMD */
+    if (const char *v = getenv("RT_AMD_DIST_CHAIN_WAVES")) { /* A/B: waves per SIMD of the chain kernel's grid */
+        const uint32_t per_simd = (uint32_t)atoi(v);
+        if (per_simd >= 1u && per_simd <= (uint32_t)RT_DIST_CHAIN_MIN_WAVES) chain_waves = resident_waves / 3u * per_simd;
+    }
     if (waves > chain_waves) waves = chain_waves;
     hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     if (after_chain != nullptr) {

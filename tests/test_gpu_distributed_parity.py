@@ -109,6 +109,43 @@ def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
     assert np.array_equal(rng.download(), st)
 
 
+@pytest.mark.parametrize("depth", [13, 32])
+def test_deep_chains(ctx, depth):
+    """More request slots than the shade kernel's default tile can list in LDS: it shrinks its tile (33 slots at depth 32)."""
+    world, camera, scene = ctx
+    frame = rt.Frame.full(40, 30, depth)
+    rng, s, v, casts = _run_gpu(scene, camera, frame, 3)
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 3)
+    assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(v, wv) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
+def test_two_tiles_on_two_streams(ctx):
+    """Two tiles of one scene, each with its own rt_rng, rendered from two streams at once (per-stream workspaces, each
+    rt_rng's own look-ahead stream): same samples as one after the other."""
+    import torch
+
+    world, camera, scene = ctx
+    frames = [rt.Frame.rows_of_rank(96, 64, 6, 0, 2), rt.Frame.rows_of_rank(96, 64, 6, 1, 2)]
+    want = []
+    for f in frames:
+        _, s, v, _ = _run_gpu(scene, camera, f, 5)
+        want.append((s, v))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rngs = [rt.Rng(f) for f in frames]
+    outs = [torch.empty((5, f.rows, f.cols, 3), dtype=torch.float32, device="cuda") for f in frames]
+    flags = [torch.empty((5, f.rows, f.cols), dtype=torch.uint8, device="cuda") for f in frames]
+    torch.cuda.synchronize()
+    for first, n in ((0, 2), (2, 3)):  # two calls per stream, interleaved between the streams
+        for k in range(2):
+            rt.render_distributed(scene, camera, frames[k], rngs[k], n, samples=outs[k][first:first + n], valid=flags[k][first:first + n], stream=streams[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(outs[k].cpu().numpy().view(np.uint32), want[k][0].view(np.uint32))
+        assert np.array_equal(flags[k].cpu().numpy(), want[k][1])
+
+
 def test_accumulate_only_call_equals_the_sample_outputs(ctx):
     """d_samples / d_valid / d_ray_count are optional: the accumulator alone must see the same sums."""
     import torch
