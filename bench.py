@@ -43,6 +43,7 @@ def parse_args():
     p.add_argument("--depth", type=int, default=8)
     p.add_argument("--variant", type=int, default=None, help="kernel variant (include/rt_amd.h): 18 = persistent workgroup-local wavefronts (default); per-pixel kernel: bit 0 LDS broadcast (else SGPR), bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase; 8 cooperative")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass's extra measurement (N = 1 only, after the timed region)")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
     return p.parse_args()
 
@@ -88,6 +89,36 @@ def cpu_baseline(world_desc, camera, width, height, depth, threads, gpu_frame):
         same = bool(np.array_equal(img.view(np.uint32), gpu_frame.view(np.uint32)))
         out["gpu_frame_bit_identical_to_cpu"] = same
     return out
+
+
+def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, calls=2):
+    """The other render loop of the reference (distributed_ray_trace with depth of field, main.rs:1117-1175; configs[3]'s
+    per-GPU work), timed after the headline measurement: samples per second of rt_render_distributed on the same
+    scene and size, once the pixels' random streams have drifted out of step (`burn` untimed epochs)."""
+    import torch
+
+    import homework_18_graphics_raytracer_amd as rt
+
+    frame = rt.Frame.full(width, height, depth)
+    rng = rt.Rng(frame)
+    accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, camera, frame, rng, burn, accum=accum)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(calls):
+        rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, ray_count=cnt)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    samples = frame.rows * frame.cols * epochs * calls
+    casts = int(cnt.item())
+    del rng, accum
+    return {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + distributed_ray_trace of one pixel)",
+            "value": round(samples / ms / 1e3, 2), "unit": "Msamples/s", "ms_per_epoch": round(ms / (epochs * calls), 4),
+            "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_sample": round(casts / samples, 3),
+            "epochs_timed": epochs * calls, "epochs_burn_in": burn, "parity": "tests/test_gpu_distributed_parity.py"}
 
 
 def main() -> int:
@@ -258,6 +289,8 @@ def main() -> int:
         if not args.no_cpu_baseline and world_size == 1:
             gpu_frame = full.cpu().numpy() if full is not None else None
             line["cpu_baseline"] = cpu_baseline(desc, camera, W, H, D, args.cpu_threads, gpu_frame)
+        if not args.no_stochastic and world_size == 1:
+            line["stochastic_pass"] = stochastic_pass(scene, camera, W, H, D)
         print(json.dumps(line), flush=True)
 
     if distributed:

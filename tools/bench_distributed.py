@@ -69,8 +69,8 @@ print(json.dumps({
     "pass": "distributed", "split": a.split, "burn": a.burn, "width": a.width, "height": a.height, "depth": a.depth, "tile_pixels": pixels,
     "epochs_per_call": a.epochs, "calls": a.calls, "ms_per_epoch": round(ms / (a.epochs * a.calls), 4),
     "Msamples_per_s": round(samples / ms / 1e3, 2), "Mrays_per_s": round(casts / ms / 1e3, 2),
-    "casts_per_sample": round(casts / samples, 3), "rng_state_GB": round(pixels * 2064 / 1e9, 3),
+    "casts_per_sample": round(casts / samples, 3), "rng_state_GB": round(pixels * 4128 / 1e9, 3),
     "rng_seed_ms": round(t_seed * 1e3, 2),
     "rng_algorithmic_bytes_per_sample_if_reloaded_every_epoch": 4128,
-    "rng_bytes_per_sample_this_kernel": round(2 * 2064 / a.epochs + 12 / a.epochs, 1),
+    "rng_note": "two 2064 B banks per pixel stay in HBM; a visit reads the words it draws (~40 B per sample) and the look-ahead pass moves 3 KB per 256-word block (~120 B per sample); measured HBM traffic of all kernels: profiles/r01_dist_split_pmc.txt",
 }))
