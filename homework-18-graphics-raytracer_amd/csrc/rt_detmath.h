@@ -168,6 +168,24 @@ RT_HD float cosf(float x) {
     return (float)v;
 }
 
+/* sinf(x) and cosf(x) of the same argument: one reduction and one evaluation of each kernel instead of two reductions
+ * and, in a wave whose lanes fall into different quadrants, two evaluations of each kernel per function.  Same
+ * operations on the same values as sinf / cosf above, so the same results bit for bit. */
+RT_HD void sincosf(float x, float *s, float *c) {
+    if (is_nan(x) || is_inf(x)) {
+        *s = quiet_nan();
+        *c = quiet_nan();
+        return;
+    }
+    int32_t q;
+    const double r = reduce_pio2(x, &q);
+    const double sk = sin_kernel(r), ck = cos_kernel(r);
+    const double sv = (q & 1) ? ck : sk;
+    const double cv = (q & 1) ? sk : ck;
+    *s = (x == 0.0f) ? x : (float)((q & 2) ? -sv : sv);
+    *c = (float)(((q + 1) & 2) ? -cv : cv);
+}
+
 RT_HD float tanf(float x) {
     if (is_nan(x) || is_inf(x)) return quiet_nan();
     if (x == 0.0f) return x; /* tan(+-0) = +-0 */
@@ -371,6 +389,7 @@ RT_HD int32_t f32_as_i32(float x) {
 namespace fake {
 RT_HD float sinf(float x) { return x * 0.5f; }
 RT_HD float cosf(float x) { return 1.0f - x * 0.25f; }
+RT_HD void sincosf(float x, float *s, float *c) { *s = x * 0.5f; *c = 1.0f - x * 0.25f; }
 RT_HD float acosf(float x) { return 1.5f - x; }
 RT_HD float atan2f(float y, float x) { return y + x; }
 RT_HD float powf(float x, float y) { return x * 0.5f + y * 1e-6f; }

@@ -611,8 +611,10 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
                 const V3 lobe = kind == 0u ? -h.normal : h_in_dir;
                 const float phi = rtdm::acosf(rtdm::powf(1.0f - gen_range_f32(rng, 0.0f, 1.0f), exponent));
                 const float theta = gen_range_f32(rng, -RT_F_PI, RT_F_PI);
-                const float sphi = rtdm::sinf(phi), cphi = rtdm::cosf(phi);
-                sdir = adjust_normal(v3(sphi * rtdm::cosf(theta), sphi * rtdm::sinf(theta), cphi), normalize(lobe));
+                float sphi, cphi, stheta, ctheta;
+                rtdm::sincosf(phi, &sphi, &cphi);
+                rtdm::sincosf(theta, &stheta, &ctheta);
+                sdir = adjust_normal(v3(sphi * ctheta, sphi * stheta, cphi), normalize(lobe));
                 const float cosine = -dot(h.normal, sdir);
                 if (cosine <= 0.0f) { /* main.rs:560, 579, 598 */
                     value = v3(0.0f, 0.0f, 0.0f);
@@ -982,8 +984,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 const V3 lobe = kind == 0u ? -h.normal : h_in_dir;
                 const float phi = rtdm::acosf(rtdm::powf(1.0f - gen_range_f32(rng, 0.0f, 1.0f), exponent));
                 const float theta = gen_range_f32(rng, -RT_F_PI, RT_F_PI);
-                const float sphi = rtdm::sinf(phi), cphi = rtdm::cosf(phi);
-                sdir = adjust_normal(v3(sphi * rtdm::cosf(theta), sphi * rtdm::sinf(theta), cphi), normalize(lobe));
+                float sphi, cphi, stheta, ctheta;
+                rtdm::sincosf(phi, &sphi, &cphi);
+                rtdm::sincosf(theta, &stheta, &ctheta);
+                sdir = adjust_normal(v3(sphi * ctheta, sphi * stheta, cphi), normalize(lobe));
                 const float cosine = -dot(h.normal, sdir);
                 if (!(cosine <= 0.0f)) { /* else black (main.rs:560, 579, 598) */
                     if (kind != 2u) { /* get_reflect(&scattered_hit) (main.rs:328-341) */

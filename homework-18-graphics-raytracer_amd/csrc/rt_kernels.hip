@@ -851,6 +851,12 @@ __host__ __device__ float math_eval_one(int op, float x, float y) {
         case RT_MATH_F64_DIV_HI: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits((double)x / (double)y) >> 32));
         case RT_MATH_F64_DIV_LO: return rtdm::f32_from_bits((uint32_t)(rtdm::f64_bits((double)x / (double)y)));
         case RT_MATH_ROUND: return rtdm::f_round(x);
+        case RT_MATH_SINCOS_SIN:
+        case RT_MATH_SINCOS_COS: {
+            float s, c;
+            rtdm::sincosf(x, &s, &c);
+            return op == RT_MATH_SINCOS_SIN ? s : c;
+        }
         default: return 0.0f;
     }
 }

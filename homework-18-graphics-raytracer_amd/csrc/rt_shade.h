@@ -53,7 +53,8 @@ RT_HD V3 adjust_normal(V3 mn, V3 normal) {
         if (ulps_eq(axis.x, 0.0f) && ulps_eq(axis.y, 0.0f) && ulps_eq(axis.z, 0.0f)) axis = cross(v3(0.0f, 1.0f, 0.0f), src);
         axis = normalize(axis);
         const float half = RT_F_PI * 0.5f; /* Rad::turn_div_2() * 0.5 */
-        const float s = rtdm::sinf(half), c = rtdm::cosf(half);
+        float s, c;
+        rtdm::sincosf(half, &s, &c);
         qs = c;
         qv = axis * s;
     } else {
@@ -93,7 +94,9 @@ RT_HD Mat material_approx(const rt_material &m, float u, float v) {
     }
     if (m.normal_fn == RT_NORMAL_WAVE_U) {
         const float angle = u * m.normal_frequency * 2.0f * RT_F_PI;
-        const V3 w = v3(rtdm::sinf(angle), 0.0f, rtdm::cosf(angle));
+        float wave_s, wave_c;
+        rtdm::sincosf(angle, &wave_s, &wave_c);
+        const V3 w = v3(wave_s, 0.0f, wave_c);
         c.normal = (dot(w, v3(0.0f, 0.0f, 1.0f)) <= 0.0f) ? -w : w;
     } else {
         c.normal = v3(m.normal[0], m.normal[1], m.normal[2]);

@@ -296,7 +296,8 @@ typedef enum rt_math_op {
     RT_MATH_F32_DIV = 6, RT_MATH_F32_SQRT = 7,
     RT_MATH_F64_SQRT_HI = 8, RT_MATH_F64_SQRT_LO = 9,   /* sqrt((double)x * (double)y) */
     RT_MATH_F64_DIV_HI = 10, RT_MATH_F64_DIV_LO = 11,   /* (double)x / (double)y */
-    RT_MATH_ROUND = 12
+    RT_MATH_ROUND = 12,
+    RT_MATH_SINCOS_SIN = 13, RT_MATH_SINCOS_COS = 14    /* the two results of the fused sincosf the kernels call */
 } rt_math_op;
 int rt_math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
 int rt_math_eval_device(int op, const float *h_x, const float *h_y, float *h_out, size_t n);

@@ -9,7 +9,7 @@ from homework_18_graphics_raytracer_amd import _capi
 pytestmark = pytest.mark.gpu
 
 OPS = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "atan2": 4, "pow": 5, "f32_div": 6, "f32_sqrt": 7,
-       "f64_sqrt_hi": 8, "f64_sqrt_lo": 9, "f64_div_hi": 10, "f64_div_lo": 11, "round": 12}
+       "f64_sqrt_hi": 8, "f64_sqrt_lo": 9, "f64_div_hi": 10, "f64_div_lo": 11, "round": 12, "sincos_sin": 13, "sincos_cos": 14}
 
 
 def _both(op, x, y):
