@@ -1052,25 +1052,57 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 /* get_shade (main.rs:407-464) for every request of the batch.  The request arrays are sparse — slot k of a sample is in
  * use only if its chain got that far (90 % at slot 0, a few per cent at slot 8) — so a workgroup first lists the live
  * (slot, sample) pairs of its `tile` samples in LDS and its waves then work through the list 64 at a time with
- * every lane busy.  No global atomics; the order within the list does not matter (each result has its own address). */
-__global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile) {
-    extern __shared__ uint32_t shade_list[]; /* [0] count, then slot << 24 | sample - tile0 */
+ * every lane busy.  No global atomics; the order within the list does not matter (each result has its own address) —
+ * which is used a second time: a light behind the surface needs no shadow cast (main.rs:431), on average one of the
+ * scene's three, and a wave skips a light only when none of its lanes needs it.  So the list is bucket-sorted by which of
+ * the first three lights face the GEOMETRIC normal (a guess at the reference's test, which uses the material's adjusted
+ * normal: it only orders the work), and most waves then hold requests that need the same lights. */
+#define DIST_SHADE_HDR 32u /* words before the lists: [0] requests, [1..8] bucket sizes, [9..16] bucket cursors */
+__global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
+    extern __shared__ uint32_t shade_lds[];
+    uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */
+    uint32_t *const shade_list = unsorted + list_cap;            /* the same, bucket by bucket */
     const uint32_t lane = threadIdx.x & 63u;
     const size_t tile0 = (size_t)blockIdx.x * tile;
-    if (threadIdx.x == 0u) shade_list[0] = 0u;
+    if (threadIdx.x < DIST_SHADE_HDR) shade_lds[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         if (tile0 + i < n_samples) {
             const uint32_t hdr = dp.sp_hdr[tile0 + i];
             const uint32_t cnt = (hdr & 0xffu) + ((hdr >> 8) & 1u);
             if (cnt != 0u) {
-                const uint32_t base = atomicAdd(&shade_list[0], cnt);
-                for (uint32_t k = 0; k < cnt; ++k) shade_list[1u + base + k] = (k << 24) | i;
+                const uint32_t base = atomicAdd(&shade_lds[0], cnt);
+                for (uint32_t k = 0; k < cnt; ++k) unsorted[base + k] = (k << 24) | i;
             }
         }
     }
     __syncthreads();
-    const uint32_t total = shade_list[0];
+    const uint32_t total = shade_lds[0];
+    const uint32_t key_lights = sort ? (sc.n_lights < 3u ? sc.n_lights : 3u) : 0u;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const uint32_t entry = unsorted[e];
+        const uint4 *r = dp.sp_req + ((size_t)(entry >> 24) * n_samples + tile0 + (entry & 0xffffu)) * 4u;
+        const uint4 a = r[0], b = r[1];
+        const V3 pos = v3(duf(a.x), duf(a.y), duf(a.z)), normal = v3(duf(b.x), duf(b.y), duf(b.z));
+        uint32_t key = 0u;
+        for (uint32_t l = 0; l < key_lights; ++l) {
+            const rt_light &L = sc.lights[l];
+            const V3 toward = L.kind == RT_LIGHT_DIRECTIONAL ? v3(L.direction[0], L.direction[1], L.direction[2])
+                                                             : pos - v3(L.origin[0], L.origin[1], L.origin[2]);
+            if (dot(toward, normal) < 0.0f) key |= 1u << l;
+        }
+        unsorted[e] = entry | (key << 16);
+        atomicAdd(&shade_lds[1u + key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const uint32_t entry = unsorted[e];
+        const uint32_t key = (entry >> 16) & 7u;
+        uint32_t at = atomicAdd(&shade_lds[9u + key], 1u);
+        for (uint32_t k = 0; k < key; ++k) at += shade_lds[1u + k];
+        shade_list[at] = entry;
+    }
+    __syncthreads();
     uint32_t casts = 0u;
     for (uint32_t first = (threadIdx.x >> 6) * 64u; first < total; first += blockDim.x) {
         const bool active = first + lane < total;
@@ -1079,8 +1111,8 @@ __global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc
         uint32_t obj = 0u, prim = 0u;
         size_t at = 0;
         if (active) {
-            const uint32_t e = shade_list[1u + first + lane];
-            at = (size_t)(e >> 24) * n_samples + tile0 + (e & 0xffffffu);
+            const uint32_t e = shade_list[first + lane];
+            at = (size_t)(e >> 24) * n_samples + tile0 + (e & 0xffffu);
             const uint4 *r = dp.sp_req + at * 4u;
             const uint4 a = r[0], b = r[1], c = r[2], d = r[3];
             pos = v3(duf(a.x), duf(a.y), duf(a.z)); u = duf(a.w);
@@ -1203,11 +1235,16 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
     }
     const size_t n_samples = (size_t)total * dp.n_epochs;
     const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
-    uint32_t tile = 512u; /* samples per workgroup: the list of their live requests must fit 48 KB of LDS */
-    while (tile > 32u && (1u + (size_t)tile * slots) * sizeof(uint32_t) > 49152u) tile >>= 1;
+    uint32_t tile = 256u; /* samples per workgroup (18 KB of LDS at depth 8: six workgroups per CU); the two lists must fit 48 KB */
+    uint32_t sort = 1u;
+    /* A/B knobs (profiles/README.md) */
+    if (const char *v = getenv("RT_AMD_SHADE_TILE")) { const uint32_t t = (uint32_t)atoi(v); if (t >= 32u && t <= 4096u) tile = t; }
+    if (const char *v = getenv("RT_AMD_SHADE_SORT")) sort = *v != '0';
+    while (tile > 32u && (DIST_SHADE_HDR + 2u * (size_t)tile * slots) * sizeof(uint32_t) > 49152u) tile >>= 1;
     const size_t shade_tiles = (n_samples + tile - 1u) / tile;
-    const size_t shade_lds = (1u + (size_t)tile * slots) * sizeof(uint32_t); /* 18 KB at depth 8 */
-    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_tiles), dim3(256), shade_lds, stream, sc, dp, n_samples, tile);
+    const uint32_t list_cap = tile * slots;
+    const size_t shade_lds = (DIST_SHADE_HDR + 2u * (size_t)list_cap) * sizeof(uint32_t);
+    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_tiles), dim3(256), shade_lds, stream, sc, dp, n_samples, tile, list_cap, sort);
     size_t blocks = ((size_t)total + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
     hipLaunchKernelGGL(dist_unwind_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp, (size_t)total, (size_t)total);
