@@ -1057,14 +1057,16 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
  * scene's three, and a wave skips a light only when none of its lanes needs it.  So the list is bucket-sorted by which of
  * the first three lights face the GEOMETRIC normal (a guess at the reference's test, which uses the material's adjusted
  * normal: it only orders the work), and most waves then hold requests that need the same lights. */
-#define DIST_SHADE_HDR 32u /* words before the lists: [0] requests, [1..8] bucket sizes, [9..16] bucket cursors */
+#define DIST_SHADE_BUCKETS 8u /* 3 bits: which of the first three lights face the surface */
+#define DIST_SHADE_HDR (1u + 2u * DIST_SHADE_BUCKETS) /* words before the lists: [0] requests, bucket sizes -> starts, bucket cursors */
 __global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
+    uint32_t *const bucket_start = shade_lds + 1u, *const bucket_cursor = bucket_start + DIST_SHADE_BUCKETS;
     uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */
     uint32_t *const shade_list = unsorted + list_cap;            /* the same, bucket by bucket */
     const uint32_t lane = threadIdx.x & 63u;
     const size_t tile0 = (size_t)blockIdx.x * tile;
-    if (threadIdx.x < DIST_SHADE_HDR) shade_lds[threadIdx.x] = 0u;
+    for (uint32_t k = threadIdx.x; k < DIST_SHADE_HDR; k += blockDim.x) shade_lds[k] = 0u;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         if (tile0 + i < n_samples) {
@@ -1078,29 +1080,34 @@ __global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc
     }
     __syncthreads();
     const uint32_t total = shade_lds[0];
-    const uint32_t key_lights = sort ? (sc.n_lights < 3u ? sc.n_lights : 3u) : 0u;
+    const uint32_t key_lights = sc.n_lights < 3u ? sc.n_lights : 3u;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         const uint32_t entry = unsorted[e];
-        const uint4 *r = dp.sp_req + ((size_t)(entry >> 24) * n_samples + tile0 + (entry & 0xffffu)) * 4u;
-        const uint4 a = r[0], b = r[1];
-        const V3 pos = v3(duf(a.x), duf(a.y), duf(a.z)), normal = v3(duf(b.x), duf(b.y), duf(b.z));
         uint32_t key = 0u;
-        for (uint32_t l = 0; l < key_lights; ++l) {
-            const rt_light &L = sc.lights[l];
-            const V3 toward = L.kind == RT_LIGHT_DIRECTIONAL ? v3(L.direction[0], L.direction[1], L.direction[2])
-                                                             : pos - v3(L.origin[0], L.origin[1], L.origin[2]);
-            if (dot(toward, normal) < 0.0f) key |= 1u << l;
+        if (sort) {
+            const uint4 *r = dp.sp_req + ((size_t)(entry >> 24) * n_samples + tile0 + (entry & 0xffffu)) * 4u;
+            const uint4 a = r[0], b = r[1];
+            const V3 pos = v3(duf(a.x), duf(a.y), duf(a.z)), normal = v3(duf(b.x), duf(b.y), duf(b.z));
+            for (uint32_t l = 0; l < key_lights; ++l) {
+                const rt_light &L = sc.lights[l];
+                const V3 toward = L.kind == RT_LIGHT_DIRECTIONAL ? v3(L.direction[0], L.direction[1], L.direction[2])
+                                                                 : pos - v3(L.origin[0], L.origin[1], L.origin[2]);
+                if (dot(toward, normal) < 0.0f) key |= 1u << l;
+            }
         }
         unsorted[e] = entry | (key << 16);
-        atomicAdd(&shade_lds[1u + key], 1u);
+        atomicAdd(&bucket_start[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < DIST_SHADE_BUCKETS) { /* sizes -> starts */
+        uint32_t before = 0u;
+        for (uint32_t k = 0; k < threadIdx.x; ++k) before += bucket_start[k];
+        bucket_cursor[threadIdx.x] = before;
     }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         const uint32_t entry = unsorted[e];
-        const uint32_t key = (entry >> 16) & 7u;
-        uint32_t at = atomicAdd(&shade_lds[9u + key], 1u);
-        for (uint32_t k = 0; k < key; ++k) at += shade_lds[1u + k];
-        shade_list[at] = entry;
+        shade_list[atomicAdd(&bucket_cursor[(entry >> 16) & (DIST_SHADE_BUCKETS - 1u)], 1u)] = entry;
     }
     __syncthreads();
     uint32_t casts = 0u;
