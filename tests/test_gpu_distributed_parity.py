@@ -109,6 +109,22 @@ def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
     assert np.array_equal(rng.download(), st)
 
 
+def test_organisations_can_alternate_on_one_rng(ctx, organisation):
+    """The two organisations share the RNG records (banks, look-ahead flags): switching between calls continues the stream."""
+    world, camera, scene = ctx
+    frame = rt.Frame.full(48, 36, 7)
+    lib = _capi.amd_lib()
+    rng, got = None, []
+    for k, n in enumerate((3, 12, 2, 30, 5)):
+        lib.rt_set_distributed_split((organisation + k) & 1)
+        rng, s, _, _ = _run_gpu(scene, camera, frame, n, rng=rng)
+        got.append(s)
+    st = _oracle.rng_init(frame)
+    ws, _, _ = _oracle.render_distributed(world.desc(), camera, frame, st, 52)
+    assert np.array_equal(np.concatenate(got).view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(rng.download(), st)
+
+
 @pytest.mark.parametrize("depth", [13, 32])
 def test_deep_chains(ctx, depth):
     """More request slots than the shade kernel's default tile can list in LDS: it shrinks its tile (33 slots at depth 32)."""
