@@ -778,7 +778,7 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
  * bit-identical to it and to the oracle (tests/test_gpu_distributed_parity.py runs both). */
 
 #ifndef RT_DIST_CHAIN_MIN_WAVES
-#define RT_DIST_CHAIN_MIN_WAVES 4
+#define RT_DIST_CHAIN_MIN_WAVES 5 /* 96 VGPRs, no more scratch than at 4 (112); 3 / 4 / 5: 709 / 853 / 868 Msamples/s */
 #endif
 
 __device__ __forceinline__ uint32_t dfu(float x) { return __float_as_uint(x); }
@@ -1059,7 +1059,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
  * normal: it only orders the work), and most waves then hold requests that need the same lights. */
 #define DIST_SHADE_BUCKETS 8u /* 3 bits: which of the first three lights face the surface */
 #define DIST_SHADE_HDR (1u + 2u * DIST_SHADE_BUCKETS) /* words before the lists: [0] requests, bucket sizes -> starts, bucket cursors */
-__global__ __launch_bounds__(256, 6) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
+#ifndef RT_DIST_SHADE_MIN_WAVES
+#define RT_DIST_SHADE_MIN_WAVES 6 /* 80 VGPRs; 4 / 5 / 8 measured in profiles/README.md */
+#endif
+__global__ __launch_bounds__(256, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
     uint32_t *const bucket_start = shade_lds + 1u, *const bucket_cursor = bucket_start + DIST_SHADE_BUCKETS;
     uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */
