@@ -109,6 +109,28 @@ def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
     assert np.array_equal(rng.download(), st)
 
 
+@pytest.mark.parametrize("focus,blur", [(3.0, 0.0), (1.5, 0.3), (8.0, 0.004), (0.5, 2.0)])
+def test_other_lens_settings_and_a_sub_rectangle(ctx, focus, blur):
+    """shoot_focus with other focus distances and aperture blurs (0: every sample through the pinhole; 2.0: origins far
+    off the lens axis), on a tile that is a sub-rectangle with a row step — seeds and clip coordinates use IMAGE x / y."""
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame(120, 90, 6, 17, 5, 83, 77, 3)
+    rng = rt.Rng(frame)
+    samples = torch.empty((4, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    valid = torch.empty((4, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, camera, frame, rng, 4, focus=focus, blur=blur, samples=samples, valid=valid, ray_count=cnt)
+    torch.cuda.synchronize()
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 4, focus=focus, blur=blur)
+    s = samples.cpu().numpy()
+    same = (s.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(s) & np.isnan(ws))
+    assert same.all() and np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
 def test_organisations_can_alternate_on_one_rng(ctx, organisation):
     """The two organisations share the RNG records (banks, look-ahead flags): switching between calls continues the stream."""
     world, camera, scene = ctx
