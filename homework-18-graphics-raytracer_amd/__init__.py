@@ -25,7 +25,7 @@ from ._capi import Camera, Frame, Light, Material, RtError, SceneDesc, Sphere, T
 
 __all__ = [
     "World", "ObjectProxy", "Scene", "Camera", "Frame", "Material", "Light", "RtError", "reference_world",
-    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "post_process_device", "encode_srgb8_device", "post_process", "encode_srgb8", "write_to_file",
+    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "render_distributed_numpy", "post_process_device", "encode_srgb8_device", "post_process", "encode_srgb8", "write_to_file",
     "DEFAULT_OBJ",
 ]
 
@@ -230,6 +230,18 @@ def render_distributed(scene: Scene, camera: Camera, frame: Frame, rng: Rng, n_e
                                               int(n_epochs), ptr(accum), ptr(samples), ptr(valid), ptr(ray_count), C.c_void_p(s.cuda_stream))
     )
     return accum if accum is not None else samples
+
+
+def render_distributed_numpy(scene: Scene, camera: Camera, frame: Frame, rng: Rng, n_epochs: int, img: np.ndarray,
+                             focus: float = 3.0, blur: float = 0.04) -> int:
+    """`n_epochs` epochs of the stochastic loop added into the host image `img` ((rows, cols, 3) f32, in place):
+    rt_render_distributed_host, the form a host-resident `img` binds (src/main.rs:1131-1167).  Returns the cast count."""
+    if not (img.dtype == np.float32 and img.flags.c_contiguous and img.shape == (frame.rows, frame.cols, 3)):
+        raise ValueError("expected a contiguous (rows, cols, 3) float32 array")
+    casts = C.c_ulonglong(0)
+    _capi.check(_capi.amd_lib().rt_render_distributed_host(scene._h, C.byref(camera), C.byref(frame), float(focus), float(blur), rng._h,
+                                                           int(n_epochs), img.ctypes.data_as(C.c_void_p), C.byref(casts)))
+    return int(casts.value)
 
 
 def post_process_device(img, divisor=None, stream=None):

@@ -1,10 +1,12 @@
 /*
- * rt_render — command-line driver: the reference's main() (src/main.rs:809-1115)
- * with the rayon render loop replaced by one call across the C ABI.
+ * rt_render — command-line driver: the reference's main() (src/main.rs:809-1175)
+ * with the two rayon render loops replaced by calls across the C ABI.
  *
- *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png]
+ *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png] [--epochs N]
  *
- * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).
+ * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).  --epochs N (default 0; the
+ * reference: 100, main.rs:1129) continues as main() does: N epochs of the depth-of-field pass (shoot_focus(3.0, 0.04),
+ * depth 5) added to the normalised image, post_process and a rewrite of the PNG after every epoch (main.rs:1129-1174).
  * Host keeps: scene build + OBJ import, post_process, sRGB/u8 encode, PNG write.
  */
 #include <chrono>
@@ -21,12 +23,14 @@ int main(int argc, char **argv) {
     int32_t depth = 5;
     const char *obj = "dodecahedron.obj";
     const char *out = "./out.png";
+    int epochs = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--width")) width = (uint32_t)atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) height = (uint32_t)atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--depth")) depth = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--obj")) obj = argv[i + 1];
         else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
+        else if (!strcmp(argv[i], "--epochs")) epochs = atoi(argv[i + 1]);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     rt_world *world = rt_world_new();
@@ -65,6 +69,29 @@ int main(int argc, char **argv) {
     if (rt_write_png(out, rgb8.data(), width, height) != RT_OK) {
         fprintf(stderr, "rt_write_png failed: %s\n", rt_host_last_error());
         return 1;
+    }
+    if (epochs > 0) {
+        rt_rng *rng = nullptr; /* main.rs:1117-1127 */
+        if (rt_rng_create(&frame, &rng) != RT_OK) {
+            fprintf(stderr, "rt_rng_create failed: %s\n", rt_last_error());
+            return 1;
+        }
+        for (int i = 0; i < epochs; ++i) {
+            t0 = std::chrono::steady_clock::now();
+            if (rt_render_distributed_host(scene, &camera, &frame, 3.0f, 0.04f, rng, 1, img.data(), &casts) != RT_OK) {
+                fprintf(stderr, "rt_render_distributed_host failed: %s\n", rt_last_error());
+                return 1;
+            }
+            ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            printf("%llu rays in %.3f ms (%.0f rays/s); %llu casts\n", pixels, ms, ms > 0 ? pixels * 1000.0 / ms : 0.0, casts);
+            rt_post_process(img.data(), (size_t)width * height); /* main.rs:1171: img itself is renormalised and kept */
+            rt_encode_srgb8(img.data(), img.size(), rgb8.data());
+            if (rt_write_png(out, rgb8.data(), width, height) != RT_OK) {
+                fprintf(stderr, "rt_write_png failed: %s\n", rt_host_last_error());
+                return 1;
+            }
+        }
+        rt_rng_destroy(rng);
     }
     rt_scene_destroy(scene);
     rt_world_free(world);

@@ -873,6 +873,35 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     return RT_OK;
 }
 
+int rt_render_distributed_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
+                               rt_rng *rng, uint32_t n_epochs, float *h_accum, unsigned long long *h_ray_count) {
+    if (!scene || !rng || !h_accum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_distributed_host: null argument");
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_distributed_host: bad frame");
+    const size_t bytes = (size_t)rt_frame_pixels(frame) * 3 * sizeof(float);
+    float *d_accum = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_accum), bytes));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_accum, h_accum, bytes, hipMemcpyHostToDevice); /* img continues from the caller's sums */
+    int rc = RT_OK;
+    if (e == hipSuccess) {
+        rc = rt_render_distributed(scene, camera, frame, focus, blur, rng, n_epochs, d_accum, nullptr, nullptr, d_cnt, nullptr);
+        if (rc == RT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(h_accum, d_accum, bytes, hipMemcpyDeviceToHost);
+            unsigned long long cnt = 0;
+            if (e == hipSuccess) e = hipMemcpy(&cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && h_ray_count) *h_ray_count = cnt;
+        }
+    }
+    (void)hipFree(d_accum);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail_hip("rt_render_distributed_host", e);
+    return RT_OK;
+}
+
 /* ---- post_process / encode on the device ----------------------------------------- */
 
 struct PostWs {

@@ -219,6 +219,13 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                           rt_rng *rng, uint32_t n_epochs, float *d_accum, float *d_samples, unsigned char *d_valid,
                           unsigned long long *d_ray_count, void *hip_stream);
 
+/* Same, with a host image: h_accum (rt_frame_pixels * 3 floats) is uploaded, n_epochs passes are ADDED to it as above
+ * and it is copied back — `img[at] = img[at] + photon` of src/main.rs:1163-1167 for n_epochs epochs in one call, which is
+ * what a host that keeps `img` in its own memory binds.  *h_ray_count is overwritten with the
+ * World::cast count of this call (may be NULL).  Synchronises. */
+int rt_render_distributed_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
+                               rt_rng *rng, uint32_t n_epochs, float *h_accum, unsigned long long *h_ray_count);
+
 /* ---- the step after the path, on the device --------------------
 
  * post_process (src/main.rs:748-762): divide the image in place by the 99th-percentile luma of its normal

@@ -226,6 +226,24 @@ def test_tile_with_row_step_matches_full_frame_rows(ctx):
     assert np.array_equal(s_band.view(np.uint32), s_full[:, 1::4].view(np.uint32)) and np.array_equal(v_band, v_full[:, 1::4])
 
 
+def test_host_image_entry_point_is_the_reference_loop(ctx):
+    """rt_render_distributed_host: img[at] = img[at] + photon for the surviving samples, epoch after epoch, continuing
+    from the caller's image and the rt_rng's streams — the reference's loop with a host-resident `img`."""
+    world, camera, scene = ctx
+    frame = rt.Frame.full(64, 40, 5)
+    rng = rt.Rng(frame)
+    img = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+    casts = rt.render_distributed_numpy(scene, camera, frame, rng, 3, img)
+    casts += rt.render_distributed_numpy(scene, camera, frame, rng, 2, img)
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 5)
+    want = np.zeros_like(img)
+    for e in range(5):
+        want = np.where(wv[e][..., None] != 0, want + ws[e], want)
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32)) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
 def test_argument_validation(ctx):
     world, camera, scene = ctx
     frame = rt.Frame.full(32, 32, 5)
