@@ -226,6 +226,26 @@ def test_tile_with_row_step_matches_full_frame_rows(ctx):
     assert np.array_equal(s_band.view(np.uint32), s_full[:, 1::4].view(np.uint32)) and np.array_equal(v_band, v_full[:, 1::4])
 
 
+def test_full_size_frame_of_the_headline_configuration(ctx, organisation):
+    """BASELINE.json's size for the stochastic configuration — 1920x1080, depth 8 — two epochs, every sample against the
+    oracle (all host threads); the split organisation also GPU against GPU with a workspace cap that forces one-epoch batches."""
+    world, camera, scene = ctx
+    frame = rt.Frame.full(1920, 1080, 8)
+    rng, s, v, casts = _run_gpu(scene, camera, frame, 2)
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 2)
+    assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(v, wv) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+    if organisation:
+        os.environ["RT_AMD_DIST_WS_MB"] = "2048"
+        try:
+            rng2, s2, v2, casts2 = _run_gpu(scene, camera, frame, 2)
+        finally:
+            del os.environ["RT_AMD_DIST_WS_MB"]
+        assert np.array_equal(s2.view(np.uint32), s.view(np.uint32)) and np.array_equal(v2, v) and casts2 == casts
+        assert np.array_equal(rng2.download(), st)
+
+
 def test_host_image_entry_point_is_the_reference_loop(ctx):
     """rt_render_distributed_host: img[at] = img[at] + photon for the surviving samples, epoch after epoch, continuing
     from the caller's image and the rt_rng's streams — the reference's loop with a host-resident `img`."""
