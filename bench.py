@@ -91,7 +91,7 @@ def cpu_baseline(world_desc, camera, width, height, depth, threads, gpu_frame):
     return out
 
 
-def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, calls=2):
+def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, calls=2, world_desc=None, cpu_threads=0):
     """The other render loop of the reference (distributed_ray_trace with depth of field, main.rs:1117-1175; configs[3]'s
     per-GPU work), timed after the headline measurement: samples per second of rt_render_distributed on the same
     scene and size, once the pixels' random streams have drifted out of step (`burn` untimed epochs)."""
@@ -115,10 +115,25 @@ def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, call
     samples = frame.rows * frame.cols * epochs * calls
     casts = int(cnt.item())
     del rng, accum
-    return {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + distributed_ray_trace of one pixel)",
-            "value": round(samples / ms / 1e3, 2), "unit": "Msamples/s", "ms_per_epoch": round(ms / (epochs * calls), 4),
-            "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_sample": round(casts / samples, 3),
-            "epochs_timed": epochs * calls, "epochs_burn_in": burn, "parity": "tests/test_gpu_distributed_parity.py"}
+    out = {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + distributed_ray_trace of one pixel)",
+           "value": round(samples / ms / 1e3, 2), "unit": "Msamples/s", "ms_per_epoch": round(ms / (epochs * calls), 4),
+           "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_sample": round(casts / samples, 3),
+           "epochs_timed": epochs * calls, "epochs_burn_in": burn, "parity": "tests/test_gpu_distributed_parity.py"}
+    if world_desc is not None:  # the oracle's restatement of the same loop on the host cores, one epoch of the same frame
+        sys.path.insert(0, str(ROOT / "tests"))
+        import _oracle
+
+        try:
+            cores = cpu_threads if cpu_threads > 0 else len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        states = _oracle.rng_init(frame)
+        t0 = time.perf_counter()
+        _, _, cpu_casts = _oracle.render_distributed(world_desc, camera, frame, states, 1, threads=cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(frame.rows * frame.cols / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "sample": f"one epoch of the same {width}x{height} depth-{depth} frame ({cpu_casts} casts, {dt:.2f} s), oracle/rt_oracle.cpp"}
+    return out
 
 
 def main() -> int:
@@ -290,7 +305,7 @@ def main() -> int:
             gpu_frame = full.cpu().numpy() if full is not None else None
             line["cpu_baseline"] = cpu_baseline(desc, camera, W, H, D, args.cpu_threads, gpu_frame)
         if not args.no_stochastic and world_size == 1:
-            line["stochastic_pass"] = stochastic_pass(scene, camera, W, H, D)
+            line["stochastic_pass"] = stochastic_pass(scene, camera, W, H, D, world_desc=None if args.no_cpu_baseline else desc, cpu_threads=args.cpu_threads)
         print(json.dumps(line), flush=True)
 
     if distributed:
