@@ -208,6 +208,28 @@ __device__ __forceinline__ float gen_range_f32(Rng &r, float low, float high) {
     const float value1_2 = rtdm::f32_from_bits((next_u32(r) >> 9) | 0x3f800000u);
     return value1_2 * scale + offset;
 }
+/* the same from a word already drawn */
+__device__ __forceinline__ float range_f32_of(uint32_t word, float low, float high) {
+    const float scale = high - low;
+    const float offset = low - scale;
+    const float value1_2 = rtdm::f32_from_bits((word >> 9) | 0x3f800000u);
+    return value1_2 * scale + offset;
+}
+/* the next three words of the stream: when they are in the current block, three loads in flight together instead of three
+ * load latencies one after the other (a pixel's block is out of the caches again between two visits) */
+__device__ __forceinline__ void next_u32x3(Rng &r, uint32_t *w0, uint32_t *w1, uint32_t *w2) {
+    if (r.index <= 253u) {
+        const uint32_t *p = r.st + RNG_RESULTS + r.index;
+        *w0 = p[0];
+        *w1 = p[1];
+        *w2 = p[2];
+        r.index += 3u;
+    } else {
+        *w0 = next_u32(r);
+        *w1 = next_u32(r);
+        *w2 = next_u32(r);
+    }
+}
 __device__ __forceinline__ double open01_f64(Rng &r) {
     const unsigned long long fraction = next_u64(r) >> 12;
     return rtdm::f64_from_bits(fraction | 0x3ff0000000000000ull) - (1.0 - 2.220446049250313e-16 / 2.0);
@@ -237,6 +259,35 @@ __device__ double standard_normal(Rng &r) {
         const double pdf = z < -700.0 ? 0.0 : rtdm::exp_mid(z);
         if (ZIG_F[i + 1u] + (ZIG_F[i] - ZIG_F[i + 1u]) * standard_f64(r) < pdf) return x;
     }
+}
+
+/* the ziggurat's immediate accept (98.8 % of the draws) on 64 bits already drawn; false: the caller takes standard_normal */
+__device__ __forceinline__ bool standard_normal_fast(unsigned long long bits, double *out) {
+    const uint32_t i = (uint32_t)(bits & 0xffull);
+    const double u = rtdm::f64_from_bits((bits >> 12) | 0x4000000000000000ull) - 3.0;
+    const double x = u * ZIG_X[i];
+    const double test_x = x < 0.0 ? -x : x;
+    *out = x;
+    return test_x < ZIG_X[i + 1u];
+}
+
+/* two StandardNormal draws in stream order.  Usually both accept at once and their four words are in the current block:
+ * then the four loads travel together; otherwise redo both the ordinary way from the same position (same draws). */
+__device__ __forceinline__ void standard_normal_x2(Rng &r, double *n0, double *n1) {
+    if (r.index <= 252u) {
+        const uint32_t *p = r.st + RNG_RESULTS + r.index;
+        const unsigned long long a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+        double x0, x1;
+        const bool f0 = standard_normal_fast((a1 << 32) | a0, &x0), f1 = standard_normal_fast((a3 << 32) | a2, &x1);
+        if (f0 && f1) {
+            *n0 = x0;
+            *n1 = x1;
+            r.index += 4u;
+            return;
+        }
+    }
+    *n0 = standard_normal(r);
+    *n1 = standard_normal(r);
 }
 
 __global__ __launch_bounds__(256) void rng_seed_kernel(uint32_t *states, uint32_t cols, uint32_t rows, uint32_t x0, uint32_t y0, uint32_t y_step) {
@@ -832,8 +883,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 
     auto start_epoch = [&]() { /* Camera::shoot_focus (main.rs:101-127) */
         const V3 direction = normalize(clip_x * cam_x + clip_y * cam_y + cam_t);
-        const float xoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng));
-        const float yoffset = (float)(0.0 + (double)dp.blur * standard_normal(rng));
+        double nx, ny;
+        standard_normal_x2(rng, &nx, &ny);
+        const float xoffset = (float)(0.0 + (double)dp.blur * nx);
+        const float yoffset = (float)(0.0 + (double)dp.blur * ny);
         req.d = normalize(direction * dp.focus + cam_x * xoffset + cam_y * yoffset);
         req.o = cam_o - (cam_x * xoffset + cam_y * yoffset);
         req.mode = FACE_FRONT;
@@ -970,7 +1023,9 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 wsum = wsum + w0;
                 wsum = wsum + w1;
                 wsum = wsum + w2;
-                const float rsel = gen_range_f32(rng, 0.0f, wsum);
+                uint32_t word_sel, word_phi, word_theta; /* the level's three draws, in stream order */
+                next_u32x3(rng, &word_sel, &word_phi, &word_theta);
+                const float rsel = range_f32_of(word_sel, 0.0f, wsum);
                 float acc = 0.0f;
                 acc += w0;
                 kind = 2u;
@@ -982,8 +1037,8 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 /* scatter_hit (main.rs:539-554) */
                 const float exponent = kind == 0u ? 1.0f : rm.smoothness;
                 const V3 lobe = kind == 0u ? -h.normal : h_in_dir;
-                const float phi = rtdm::acosf(rtdm::powf(1.0f - gen_range_f32(rng, 0.0f, 1.0f), exponent));
-                const float theta = gen_range_f32(rng, -RT_F_PI, RT_F_PI);
+                const float phi = rtdm::acosf(rtdm::powf(1.0f - range_f32_of(word_phi, 0.0f, 1.0f), exponent));
+                const float theta = range_f32_of(word_theta, -RT_F_PI, RT_F_PI);
                 float sphi, cphi, stheta, ctheta;
                 rtdm::sincosf(phi, &sphi, &cphi);
                 rtdm::sincosf(theta, &stheta, &ctheta);
