@@ -1117,7 +1117,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 #ifndef RT_DIST_SHADE_MIN_WAVES
 #define RT_DIST_SHADE_MIN_WAVES 6 /* 80 VGPRs; 4 / 5 / 8 measured in profiles/README.md */
 #endif
-__global__ __launch_bounds__(256, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
+#ifndef RT_DIST_SHADE_THREADS
+#define RT_DIST_SHADE_THREADS 256
+#endif
+__global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
     uint32_t *const bucket_start = shade_lds + 1u, *const bucket_cursor = bucket_start + DIST_SHADE_BUCKETS;
     uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */
@@ -1309,7 +1312,7 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
     const size_t shade_tiles = (n_samples + tile - 1u) / tile;
     const uint32_t list_cap = tile * slots;
     const size_t shade_lds = (DIST_SHADE_HDR + 2u * (size_t)list_cap) * sizeof(uint32_t);
-    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_tiles), dim3(256), shade_lds, stream, sc, dp, n_samples, tile, list_cap, sort);
+    hipLaunchKernelGGL(dist_shade_kernel, dim3((unsigned)shade_tiles), dim3(RT_DIST_SHADE_THREADS), shade_lds, stream, sc, dp, n_samples, tile, list_cap, sort);
     size_t blocks = ((size_t)total + 255u) / 256u;
     if (blocks > 4096u) blocks = 4096u;
     hipLaunchKernelGGL(dist_unwind_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dp, (size_t)total, (size_t)total);
