@@ -808,31 +808,46 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         const uint32_t slots = (uint32_t)(kf.max_depth > 0 ? kf.max_depth : 0) + 1u;
         const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
         uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
-        auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
-        const size_t n_samples = n_pixels * batch;
-        size_t off = 0;
-        const size_t o_hdr = carve(off, n_samples * sizeof(uint32_t));
-        const size_t o_req = carve(off, n_samples * slots * 4u * sizeof(uint4));
-        const size_t o_shade = carve(off, n_samples * slots * sizeof(float4));
-        const size_t o_frame = carve(off, n_samples * (slots - 1u) * sizeof(float4));
+        size_t o_hdr = 0, o_req = 0, o_shade = 0, o_frame = 0;
+        auto layout = [&](uint32_t epochs) { /* -> bytes */
+            auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
+            const size_t n_samples = n_pixels * epochs;
+            size_t off = 0;
+            o_hdr = carve(off, n_samples * sizeof(uint32_t));
+            o_req = carve(off, n_samples * slots * 4u * sizeof(uint4));
+            o_shade = carve(off, n_samples * slots * sizeof(float4));
+            o_frame = carve(off, n_samples * (slots - 1u) * sizeof(float4));
+            return off;
+        };
         char *base = nullptr;
         {
             std::lock_guard<std::mutex> lock(mut->ws_mutex);
             Workspace &ws = mut->workspaces[stream];
             if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
-            if (ws.split_bytes < off) {
+            size_t need = layout(batch);
+            if (ws.split_bytes < need) {
                 if (ws.d_split) {
                     RT_HIP(hipStreamSynchronize(stream));
                     RT_HIP(hipFree(ws.d_split));
                     ws.d_split = nullptr;
                     ws.split_bytes = 0;
                 }
-                RT_HIP(hipMalloc(&ws.d_split, off));
-                ws.split_bytes = off;
+                /* no room for the batch the cap allows: halve it; no room for one epoch: the one-kernel organisation */
+                int refuse = 0; /* test hook: pretend the first n allocations fail (tests/test_gpu_distributed_parity.py) */
+                if (const char *v = getenv("RT_AMD_DIAG_WS_REFUSE")) refuse = atoi(v);
+                while (refuse-- > 0 || hipMalloc(&ws.d_split, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ws.d_split = nullptr;
+                    if (batch == 1u) break;
+                    batch = (batch + 1u) / 2u;
+                    need = layout(batch);
+                }
+                ws.split_bytes = ws.d_split ? need : 0;
             }
             dp.work_queue = ws.d_counters;
             base = static_cast<char *>(ws.d_split);
         }
+        if (base == nullptr) goto one_kernel;
         dp.sp_hdr = reinterpret_cast<uint32_t *>(base + o_hdr);
         dp.sp_req = reinterpret_cast<uint4 *>(base + o_req);
         dp.sp_shade = reinterpret_cast<float4 *>(base + o_shade);
@@ -853,6 +868,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         }
         return RT_OK;
     }
+one_kernel:
+    dp.n_epochs = n_epochs;
     dp.epoch0 = 0;
     dp.sp_hdr = nullptr; dp.sp_req = nullptr; dp.sp_shade = nullptr; dp.sp_frame = nullptr; dp.sp_slots = 0;
     {

@@ -274,7 +274,8 @@ int rt_set_wavefront_budget(unsigned nodes_per_pixel);
 /* rt_render_distributed has two organisations with bit-identical results (samples, flags, RNG states, cast counts):
  *   1 (default)  three kernels per batch of epochs — the scatter chain with all random draws, every get_shade it
  *                asked for, the unwind + filter + accumulation — over a per-stream workspace (852 B per sample at depth 8,
- *                at most RT_AMD_DIST_WS_MB MiB, default 16384; a batch is as many epochs as fit, 16 at most);
+ *                at most RT_AMD_DIST_WS_MB MiB, default 16384; a batch is as many epochs as fit, 16 at most, and fewer if the device
+ *                cannot provide the memory — down to organisation 0 when not even one epoch fits);
  *   0            one kernel, a lane stays on its pixel through chain, shades and unwind (no workspace).
  * -1 restores the default / the RT_AMD_DIST_SPLIT environment variable. */
 int rt_set_distributed_split(int on);

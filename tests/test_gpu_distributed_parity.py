@@ -246,6 +246,26 @@ def test_full_size_frame_of_the_headline_configuration(ctx, organisation):
         assert np.array_equal(rng2.download(), st)
 
 
+@pytest.mark.parametrize("refuse", ["1", "3", "99"])
+def test_workspace_that_cannot_be_allocated_means_smaller_batches_then_one_kernel(ctx, organisation, refuse):
+    """No device memory for the batch the cap allows: the batch is halved until it fits; not even one epoch fits: the
+    one-kernel organisation renders the call.  Same samples either way (the hook makes the first n allocations fail)."""
+    if not organisation:
+        pytest.skip("the one-kernel organisation has no workspace")
+    world, camera, _ = ctx
+    scene = rt.Scene(world)  # a scene of its own: the workspace is kept per scene and stream, this one must be new
+    frame = rt.Frame.full(50, 38, 6)
+    os.environ["RT_AMD_DIAG_WS_REFUSE"] = refuse
+    try:
+        rng, s, v, casts = _run_gpu(scene, camera, frame, 7)
+    finally:
+        del os.environ["RT_AMD_DIAG_WS_REFUSE"]
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 7)
+    assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(v, wv) and casts == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
 def test_host_image_entry_point_is_the_reference_loop(ctx):
     """rt_render_distributed_host: img[at] = img[at] + photon for the surviving samples, epoch after epoch, continuing
     from the caller's image and the rt_rng's streams — the reference's loop with a host-resident `img`."""
