@@ -568,9 +568,15 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 if (ws.d_pwf) (void)hipFree(ws.d_pwf);
                 ws.d_pwf = nullptr;
                 ws.pwf_bytes = 0;
-                RT_HIP(hipMalloc(&ws.d_pwf, need));
-                ws.pwf_bytes = need;
+                const char *refuse = getenv("RT_AMD_DIAG_WS_REFUSE"); /* test hook: pretend the allocation fails */
+                if ((refuse && atoi(refuse) > 0) || hipMalloc(&ws.d_pwf, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ws.d_pwf = nullptr;
+                } else {
+                    ws.pwf_bytes = need;
+                }
             }
+            if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
             pw.tile_order = g_diag_tile_order;
             pw.global = static_cast<uint32_t *>(ws.d_pwf);
             pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 128);

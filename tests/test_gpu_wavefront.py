@@ -156,3 +156,16 @@ def test_two_streams_render_concurrently_with_their_own_workspaces(ref):
         torch.cuda.synchronize()
         for k in range(2):
             assert torch.equal(outs[k].view(torch.int32), want[k].view(torch.int32))
+
+
+def test_no_memory_for_the_arenas_means_the_per_pixel_kernel(ref):
+    """If the arenas cannot be allocated the frame is rendered by the per-pixel kernel in the same call (the hook makes
+    the allocation fail; a scene of its own, because the workspace is kept per scene and stream)."""
+    import os
+
+    world, cam, _ = ref
+    os.environ["RT_AMD_DIAG_WS_REFUSE"] = "1"
+    try:
+        _check(world, cam, rt.Frame.full(200, 150, 6), scene=rt.Scene(world))
+    finally:
+        del os.environ["RT_AMD_DIAG_WS_REFUSE"]
