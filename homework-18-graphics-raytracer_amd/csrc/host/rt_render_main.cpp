@@ -3,10 +3,13 @@
  * with the two rayon render loops replaced by calls across the C ABI.
  *
  *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png] [--epochs N]
+ *             [--focus F] [--blur B]
  *
  * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).  --epochs N (default 0; the
- * reference: 100, main.rs:1129) continues as main() does: N epochs of the depth-of-field pass (shoot_focus(3.0, 0.04),
- * depth 5) added to the normalised image, post_process and a rewrite of the PNG after every epoch (main.rs:1129-1174).
+ * reference: 100, main.rs:1129) continues as main() does: N epochs of the depth-of-field pass (shoot_focus(focus, blur),
+ * defaults 3.0 / 0.04 = main.rs:1147-1148; depth 5) added to the normalised image, post_process and a rewrite of the PNG
+ * after every epoch (main.rs:1129-1174).  `--epochs 7` reproduces report/out.png, `--epochs 7 --blur 0.02`
+ * report/out_small_blur.png (tests/test_gpu_reference_pins.py).
  * Host keeps: scene build + OBJ import, post_process, sRGB/u8 encode, PNG write.
  */
 #include <chrono>
@@ -24,6 +27,7 @@ int main(int argc, char **argv) {
     const char *obj = "dodecahedron.obj";
     const char *out = "./out.png";
     int epochs = 0;
+    float focus = 3.0f, blur = 0.04f; /* main.rs:1147-1148 */
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--width")) width = (uint32_t)atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) height = (uint32_t)atoi(argv[i + 1]);
@@ -31,6 +35,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--obj")) obj = argv[i + 1];
         else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
         else if (!strcmp(argv[i], "--epochs")) epochs = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--focus")) focus = strtof(argv[i + 1], nullptr);
+        else if (!strcmp(argv[i], "--blur")) blur = strtof(argv[i + 1], nullptr);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     rt_world *world = rt_world_new();
@@ -78,7 +84,7 @@ int main(int argc, char **argv) {
         }
         for (int i = 0; i < epochs; ++i) {
             t0 = std::chrono::steady_clock::now();
-            if (rt_render_distributed_host(scene, &camera, &frame, 3.0f, 0.04f, rng, 1, img.data(), &casts) != RT_OK) {
+            if (rt_render_distributed_host(scene, &camera, &frame, focus, blur, rng, 1, img.data(), &casts) != RT_OK) {
                 fprintf(stderr, "rt_render_distributed_host failed: %s\n", rt_last_error());
                 return 1;
             }

@@ -55,6 +55,24 @@ def test_wavefront_reference_size(ref, variant):
     _check(world, cam, rt.Frame.full(1280, 960, 5), scene=scene, variant=variant)
 
 
+HEADLINE_CASTS = 17756787  # World::cast evaluations of the 1920x1080 depth-8 frame (oracle; BENCH_r01's ray count)
+
+
+def test_headline_configuration_device_path(ref):
+    """BASELINE.json configs[1]/[2], the configuration the metric is quoted on: 1920x1080, depth 8, the Whitted loop
+    (main.rs:1087-1109), through the stream-ordered device entry point bench.py times — radiance as u32 and the cast
+    count against the oracle."""
+    import torch
+
+    world, cam, scene = ref
+    frame = rt.Frame.full(1920, 1080, 8)
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    got = rt.render_whitted(scene, cam, frame, ray_count=count).cpu().numpy()
+    want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
+    assert wcasts == HEADLINE_CASTS and int(count.item()) == HEADLINE_CASTS
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("variant", PATHS)
 @pytest.mark.parametrize("budget", [1, 2, 3])
 def test_budget_overflow_falls_back_to_the_per_pixel_kernel(ref, budget, variant):

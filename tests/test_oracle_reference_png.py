@@ -66,3 +66,66 @@ def test_glibc_libm_variant_is_close_but_not_closer(setup, ref_png):
     assert np.mean(np.abs(u_l - ref_png) <= 1) >= 0.9999
     assert np.mean(u_d == ref_png) >= np.mean(u_l == ref_png)
     assert np.mean(u_l == u_d) >= 0.9995
+
+
+# ---- the stochastic pass: main()'s progressive loop, pinned per pixel -------------------------------------------------
+#
+# report/out.png and report/out_small_blur.png (tests/golden/ref_out_distributed.png, ref_out_small_blur.png) are the
+# files main() had rewritten after its SEVENTH depth-of-field epoch (the author stopped the 100-epoch loop there):
+# Whitted frame -> post_process -> 7 x {one epoch of shoot_focus(3.0, blur) + distributed_ray_trace added where all three
+# channels are normal, post_process} -> sRGB/u8 (main.rs:1087-1173), with blur 0.04 (main.rs:1148's literal) for out.png
+# and 0.02 for out_small_blur.png.  At exactly 7 epochs the oracle reproduces both to the last u8 but for a handful of
+# channels off by one; at any other epoch count 10-18 % of the channels agree.  This pins, against reference-held
+# outputs: IsaacRng::new_from_u64(y * 2^33 + x) and its output order, Uniform<f32>, the ziggurat Normal and its
+# regenerated tables, shoot_focus, weighted_select, scatter_hit, distributed_ray_trace, the is_normal filter, the
+# accumulation into the normalised image and the in-place renormalisation.
+
+REFERENCE_EPOCHS = 7
+PINS = [(0.04, "ref_out_distributed.png"), (0.02, "ref_out_small_blur.png")]
+
+
+_whitted_cache = {}
+
+
+def _whitted_normalised(world, camera, frame):
+    key = (frame.width, frame.height, frame.max_depth)
+    if key not in _whitted_cache:
+        img, _ = _oracle.render_whitted(world.desc(), camera, frame)
+        _oracle.post_process(img)
+        _whitted_cache[key] = img
+    return _whitted_cache[key].copy()
+
+
+def progressive_loop(world, camera, frame, blur, epochs, focus=3.0):
+    """main.rs:1087-1173 on the oracle; yields (k, u8 image) after the Whitted frame (k = 0) and after every epoch."""
+    img = _whitted_normalised(world, camera, frame)
+    yield 0, _oracle.encode_srgb8(img).astype(np.int32)
+    states = _oracle.rng_init(frame)
+    for k in range(1, epochs + 1):
+        s, v, _ = _oracle.render_distributed(world.desc(), camera, frame, states, 1, focus=focus, blur=blur)
+        img += np.where(v[0][..., None] != 0, s[0], np.float32(0))  # main.rs:1157-1167
+        _oracle.post_process(img)                                    # main.rs:1171
+        yield k, _oracle.encode_srgb8(img).astype(np.int32)
+
+
+@pytest.mark.parametrize("blur,name", PINS)
+def test_oracle_progressive_loop_matches_the_reference_image_at_seven_epochs(setup, blur, name):
+    world, camera, frame = setup
+    ref = np.asarray(Image.open(_oracle.GOLDEN / name).convert("RGB")).astype(np.int32)
+    identical = {}
+    for k, u8 in progressive_loop(world, camera, frame, blur, REFERENCE_EPOCHS + 1):
+        diff = np.abs(u8 - ref)
+        identical[k] = float(np.mean(diff == 0))
+        if k == REFERENCE_EPOCHS:
+            assert diff.max() <= 1, f"max |diff| {diff.max()} at {k} epochs"
+            assert identical[k] >= 0.9999, f"only {identical[k]:.6f} of the channels identical at {k} epochs"
+    # an epoch count that drifts by one cannot pass: neighbours of 7 are far away
+    assert identical[REFERENCE_EPOCHS - 1] < 0.5 and identical[REFERENCE_EPOCHS + 1] < 0.5, identical
+
+
+def test_the_two_reference_images_differ_by_their_blur_only_in_the_stochastic_part(setup):
+    """The other blur value does not reproduce either image (so `blur` is pinned, not just the epoch count)."""
+    world, camera, frame = setup
+    ref = np.asarray(Image.open(_oracle.GOLDEN / "ref_out_small_blur.png").convert("RGB")).astype(np.int32)
+    *_, (k, u8) = progressive_loop(world, camera, frame, 0.04, REFERENCE_EPOCHS)
+    assert k == REFERENCE_EPOCHS and np.mean(u8 == ref) < 0.8

@@ -1,6 +1,9 @@
-"""The oracle's restatement of rand 0.5 (ISAAC-32, Uniform<f32>, ziggurat Normal): structural known answers.
-The crate is not in the image, so these do not pin the Rust bit streams — they pin the published
-algorithm: the ISAAC reference vector for the all-zero key, distribution moments, and stream bookkeeping."""
+"""The oracle's restatement of rand 0.5 (ISAAC-32, Uniform<f32>, ziggurat Normal): known answers.
+rand 0.5's own unit test `prng::isaac::test_isaac_new_uninitialized` (src/prng/isaac.rs) publishes the first 16 words of
+`IsaacRng::new_from_u64(0)` — the constructor main.rs:1119-1124 calls, pixel (0,0) has seed 0 — and the oracle must
+produce exactly those; Jenkins' two-pass vector, distribution moments and stream bookkeeping pin the rest.  Uniform<f32>,
+the ziggurat Normal and their use by the render loop are pinned per pixel by the two 7-epoch reference images
+(tests/test_oracle_reference_png.py)."""
 import ctypes as C
 
 import numpy as np
@@ -27,6 +30,21 @@ def test_layout_and_seed_mapping():
     assert len({bytes(s[:256].tobytes()) for s in st}) == 12
     fr2 = rt.Frame(640, 480, 5, 6, 9, 7, 10, 1)  # the single pixel (x=6, y=9)
     assert np.array_equal(_oracle.rng_init(fr2)[0], st[1 * 4 + 1])
+
+
+# rand 0.5.x src/prng/isaac.rs, #[test] fn test_isaac_new_uninitialized: IsaacRng::new_from_u64(0), 16 x next_u32()
+RAND_05_NEW_FROM_U64_0 = [
+    0x71D71FD2, 0xB54ADAE7, 0xD4788559, 0xC36129FA, 0x21DC1EA9, 0x3CB879CA, 0xD83B237F, 0xFA3CE5BD,
+    0x8D048509, 0xD82E9489, 0xDB452848, 0xCA20E846, 0x500F972E, 0x0EEFF940, 0x00D6B993, 0xBC12C17F,
+]
+
+
+def test_new_from_u64_zero_matches_rands_own_unit_test_vector():
+    """main.rs:1119-1124: `IsaacRng::new_from_u64(y * (2 << 32) + x)`; the pixel (0,0) is rand's published case."""
+    st = _state(rt.Frame(8, 8, 5, 0, 0, 1, 1, 1))[0].copy()
+    out = np.empty(16, dtype=np.uint32)
+    L.orc_rng_draw_u32(st.ctypes.data, out.ctypes.data, 16)
+    assert [int(v) for v in out] == RAND_05_NEW_FROM_U64_0
 
 
 def test_isaac_zero_key_matches_the_published_reference_vector():
