@@ -14,9 +14,10 @@
  * Whitted kernel (rt_cast.h).  get_shade(&hit) at main.rs:524 is pure and only used at depth <= 0; it is
  * evaluated there only (the oracle follows the same plan, so cast counts agree).
  *
- * rand 0.5 (ISAAC-32, Uniform<f32>, ziggurat Normal) is restated from the crate's published algorithms;
- * the crate is not in the build image, so the random bit streams are "parity unpinned" against the Rust
- * binary and pinned bit-for-bit against oracle/rt_oracle.cpp, which implements them independently.
+ * rand 0.5 (ISAAC-32, Uniform<f32>, ziggurat Normal) is restated from the crate's published algorithms (the
+ * crate is not in the build image).  Pinned: bit-for-bit against oracle/rt_oracle.cpp on every sample, flag and RNG
+ * record, and — through main()'s whole progressive loop at 7 epochs — per pixel against the reference's own
+ * report/out.png (blur 0.04) and report/out_small_blur.png (blur 0.02): tests/test_gpu_reference_pins.py.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

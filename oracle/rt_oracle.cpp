@@ -21,10 +21,19 @@
  *   rand 0.5     — IsaacRng::new_from_u64, Uniform<f32>, Normal (ziggurat)
  *
  * PARITY PIN: the reference has no tests and cannot be built here (no Rust
- * toolchain).  The only pin is report/out_single_epoch.png
- * (copied to tests/golden/ref_out_single_epoch.png), compared after
- * post_process + sRGB encode in tests/test_oracle_reference_png.py.  The
- * stochastic pass (ISAAC / ziggurat bit streams) is "parity unpinned".
+ * toolchain).  It is pinned by the three full-frame images
+ * the reference holds (tests/test_oracle_reference_png.py, all compared after
+ * post_process + sRGB/u8 encode, bar: max |diff| 1 and >= 99.99 % of the
+ * 3 686 400 channels identical):
+ *   report/out_single_epoch.png  the Whitted pass (main.rs:1087-1115)
+ *   report/out.png               Whitted + 7 depth-of-field epochs, blur 0.04
+ *   report/out_small_blur.png    the same with blur 0.02 (main.rs:1117-1173)
+ * (copies under tests/golden/), and by rand 0.5's own published vector for
+ * IsaacRng::new_from_u64(0) (tests/test_oracle_rng.py).  The stochastic pass
+ * is therefore pinned per pixel: ISAAC seeding and output order,
+ * Uniform<f32>, the ziggurat Normal and its tables, shoot_focus,
+ * weighted_select, scatter_hit, the is_normal filter and the in-place
+ * renormalisation all reproduce two reference-held images to the last u8.
  *
  * Transcendentals: by default the deterministic binary64-evaluated functions of
  * rt_detmath.h (shared with the device so CPU == GPU bit-for-bit).  Build with
@@ -638,8 +647,9 @@ static inline float luma_of(const float row[3], float r, float g, float b) {
 
 /* ------------------------------------------------------------------------- */
 /* rand 0.5: IsaacRng (ISAAC-32), Uniform<f32>, Normal (ziggurat), Open01       */
-/* Restated from the crate's published algorithms; the crate is not in this    */
-/* image, so these bit streams are "parity unpinned" (header of this file).    */
+/* Restated from the crate's published algorithms (the crate is not in this    */
+/* image); pinned by rand's new_from_u64(0) vector and by the two 7-epoch      */
+/* reference images (header of this file).                                     */
 /* ------------------------------------------------------------------------- */
 struct Isaac {
     uint32_t mem[256];
