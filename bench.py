@@ -43,7 +43,7 @@ def parse_args():
     p.add_argument("--depth", type=int, default=8)
     p.add_argument("--variant", type=int, default=None, help="kernel variant (include/rt_amd.h): 18 = persistent workgroup-local wavefronts (default); per-pixel kernel: bit 0 LDS broadcast (else SGPR), bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase; 8 cooperative")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass's extra measurement (N = 1 only, after the timed region)")
+    p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
     return p.parse_args()
 
@@ -91,36 +91,97 @@ def cpu_baseline(world_desc, camera, width, height, depth, threads, gpu_frame):
     return out
 
 
-def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, calls=2, world_desc=None, cpu_threads=0):
-    """The other render loop of the reference (distributed_ray_trace with depth of field, main.rs:1117-1175; configs[3]'s
-    per-GPU work), timed after the headline measurement: samples per second of rt_render_distributed on the same
-    scene and size, once the pixels' random streams have drifted out of step (`burn` untimed epochs)."""
+STOCHASTIC_EPOCHS = 64  # BASELINE.json configs[3]: 64 depth-of-field samples per pixel
+
+
+def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distributed, world_desc=None, cpu_threads=0,
+                    epochs=STOCHASTIC_EPOCHS):
+    """The other render loop of the reference (shoot_focus + distributed_ray_trace, main.rs:1117-1167) as BASELINE.json
+    configs[3] states it: 64 samples per pixel of the 1920x1080 depth-8 frame, image rows sharded over the ranks, the
+    accumulated bands gathered to rank 0 over RCCL.  ONE convention for every number of this pass: the whole job from
+    freshly seeded streams (IsaacRng::new_from_u64 per pixel, main.rs:1117-1127, outside the timed region exactly as it is
+    outside the reference's stopwatch), `epochs` epochs in one rt_render_distributed call per rank, the gather inside the
+    timed region, barrier + synchronize on both sides, max over ranks.  Returns the JSON object (rank 0) or None."""
     import torch
+    import torch.distributed as dist
 
     import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import dist as rtdist
 
-    frame = rt.Frame.full(width, height, depth)
-    rng = rt.Rng(frame)
+    frame = rtdist.shard_frame(width, height, depth, rank, world_size)
     accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-    rt.render_distributed(scene, camera, frame, rng, burn, accum=accum)
+    warm = rt.Rng(frame)  # untimed: sizes the workspace, loads the kernels
+    rt.render_distributed(scene, camera, frame, warm, 8, accum=accum)
+    torch.cuda.synchronize()
+    warm.close()
+    del warm
+    accum.zero_()
+    rng = rt.Rng(frame)
+    staging = None
+    if distributed and rank == 0:
+        staging = torch.empty((world_size, rtdist.band_rows(height, 0, world_size), width, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
     e0.record()
-    for _ in range(calls):
-        rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, ray_count=cnt)
+    rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, ray_count=cnt)
     e1.record()
+    full = rtdist.gather_frame(accum, height, rank, world_size, staging=staging) if distributed else accum
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    samples = frame.rows * frame.cols * epochs * calls
-    casts = int(cnt.item())
-    del rng, accum
-    out = {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + distributed_ray_trace of one pixel)",
-           "value": round(samples / ms / 1e3, 2), "unit": "Msamples/s", "ms_per_epoch": round(ms / (epochs * calls), 4),
-           "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_sample": round(casts / samples, 3),
-           "epochs_timed": epochs * calls, "epochs_burn_in": burn, "parity": "tests/test_gpu_distributed_parity.py"}
-    if world_desc is not None:  # the oracle's restatement of the same loop on the host cores, one epoch of the same frame
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    render_ms = e0.elapsed_time(e1)  # this rank's epochs alone, HIP events on the launch stream
+    t = torch.tensor([elapsed, render_ms], dtype=torch.float64, device="cuda")
+    total = cnt.clone()
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    elapsed, render_ms = float(t[0].item()), float(t[1].item())
+    samples = width * height * epochs
+    casts = int(total.item())
+    casts_rank = int(cnt.item())
+    flop_per_cast = 64 * FLOP_PER_TRIANGLE_TEST + 4 * FLOP_PER_SPHERE_TEST
+    if world_desc is not None:
+        flop_per_cast = world_desc.n_triangles * FLOP_PER_TRIANGLE_TEST + world_desc.n_spheres * FLOP_PER_SPHERE_TEST
+    tflops = casts_rank * flop_per_cast / (render_ms * 1e-3) / 1e12
+    rank_samples = frame.rows * frame.cols * epochs
+    alg_bytes = rank_samples * (12 + 2 * 2064)  # SURVEY §8(d): 12 B out + the generator's record read and written, per sample
+    out = {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + cast + distributed_ray_trace of one pixel)",
+           "value": round(samples / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world_size,
+           "ms_per_epoch": round(elapsed * 1e3 / epochs, 4), "ms_total": round(elapsed * 1e3, 3),
+           "Mrays_per_s": round(casts / elapsed / 1e6, 2), "casts_per_sample": round(casts / samples, 3),
+           "config": {"workload": f"configs[3]: {epochs} depth-of-field samples per pixel, {width}x{height}, depth {depth}, focus 3.0, blur 0.04, "
+                                  f"streams seeded y*2^33+x, interleaved rows over {world_size} rank(s)" + (", accumulators gathered to rank 0 over RCCL inside the timed region" if distributed else ""),
+                      "epochs": epochs},
+           "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
+                        "kernel": "the pass's four kernels together (rng look-ahead, dist_chain_kernel, dist_shade_kernel, dist_unwind_kernel); dist_chain_kernel is ~60 % of it",
+                        "render_ms": round(render_ms, 3), "flop_per_cast": flop_per_cast, "casts_per_launch": casts_rank,
+                        "note": "algorithmic flop = casts x (T x 77 + S x 28): an upper bound on useful work, as for the Whitted pass",
+                        "hbm": {"achieved": round(alg_bytes / (render_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(alg_bytes / (render_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes}},
+           "parity": "tests/test_gpu_distributed_parity.py, tests/test_gpu_reference_pins.py"}
+    tpath = ROOT / "profiles" / "traffic_stochastic.json"
+    if tpath.exists():
+        try:
+            rec = json.loads(tpath.read_text())
+            if rec.get("width") == width and rec.get("height") == height and rec.get("depth") == depth and rec.get("epochs") == epochs and world_size == 1:
+                out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    if world_desc is not None and world_size == 1:
+        # the oracle's restatement of the same loop on the host cores: the FIRST epoch of the same frame; the GPU's first
+        # epoch (fresh streams, same seeds) must equal it bit for bit
         sys.path.insert(0, str(ROOT / "tests"))
+        import numpy as np
         import _oracle
 
         try:
@@ -129,10 +190,19 @@ def stochastic_pass(scene, camera, width, height, depth, burn=32, epochs=8, call
             cores = os.cpu_count() or 1
         states = _oracle.rng_init(frame)
         t0 = time.perf_counter()
-        _, _, cpu_casts = _oracle.render_distributed(world_desc, camera, frame, states, 1, threads=cores)
+        want_s, want_v, cpu_casts = _oracle.render_distributed(world_desc, camera, frame, states, 1, threads=cores)
         dt = time.perf_counter() - t0
+        rng1 = rt.Rng(frame)
+        got_s = torch.empty((1, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+        got_v = torch.empty((1, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+        rt.render_distributed(scene, camera, frame, rng1, 1, samples=got_s, valid=got_v)
+        torch.cuda.synchronize()
+        gs, ws = got_s.cpu().numpy(), want_s
+        same = bool(np.array_equal(got_v.cpu().numpy(), want_v) and (((gs.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(gs) & np.isnan(ws))).all())
+                    and np.array_equal(rng1.download(), states))
         out["cpu_baseline"] = {"value": round(frame.rows * frame.cols / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "sample": f"one epoch of the same {width}x{height} depth-{depth} frame ({cpu_casts} casts, {dt:.2f} s), oracle/rt_oracle.cpp"}
+                               "sample": f"the first epoch of the same {width}x{height} depth-{depth} frame ({cpu_casts} casts, {dt:.2f} s), oracle/rt_oracle.cpp",
+                               "gpu_epoch_bit_identical_to_cpu": same}
     return out
 
 
@@ -244,15 +314,22 @@ def main() -> int:
         casts_this_rank = int(count.item()) // max(1, args.steps)
         achieved_tflops = casts_this_rank * flop_per_cast / (kernel_ms_max * 1e-3) / 1e12
         alg_hbm_bytes = frame.rows * frame.cols * 12 + 6752  # 12 B/pixel out + the scene once
-        traffic = None
+        traffic, executed = None, None
         tpath = ROOT / "profiles" / "traffic.json"
         if tpath.exists():
             try:
                 rec = json.loads(tpath.read_text())
                 if rec.get("width") == W and rec.get("height") == H and rec.get("depth") == D and world_size == 1 and rec.get("variant", 2) == variant:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    if rec.get("sq_insts_valu"):
+                        # executed VALU work from the SQ_INSTS_VALU counter of the committed profile (wave-instructions x 64
+                        # lanes), against the issue roof of a path that may not fuse multiply-add: half the FMA peak
+                        lane_ops = float(rec["sq_insts_valu"]) * 64.0
+                        tops = lane_ops / (kernel_ms_max * 1e-3) / 1e12
+                        executed = {"lane_ops_per_launch": lane_ops, "achieved": round(tops, 3), "peak_no_fma": PEAK_FP32_VECTOR_TFLOPS / 2,
+                                    "unit": "T lane-op/s", "frac": round(tops / (PEAK_FP32_VECTOR_TFLOPS / 2), 4), "source": rec.get("source")}
             except Exception:
-                traffic = None
+                traffic, executed = None, None
         line = {
             "metric": "Mrays/s (primary+secondary) at 1920x1080, depth 8",
             "value": round(mrays, 3),
@@ -279,11 +356,12 @@ def main() -> int:
             "casts_per_pixel": round(casts_per_frame / (W * H), 3),
             "roofline": {
                 "bound": "valu_fp32",
-                "achieved": round(achieved_tflops, 4),
+                "achieved": round(achieved_tflops, 4),  # ALGORITHMIC flop/s: an upper bound on useful work (see "note")
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 5),
                 "traffic": traffic,
+                "executed_valu": executed,
                 "kernel": "rt::pwf_kernel (the persistent render kernel; its two one-thread bookkeeping launches are in call_ms_avg)" if variant & 16
                           else "rt::whitted_kernel<8, false, 0> (the render launch; the probe launch of the same call is in call_ms_avg)",
                 "kernel_ms_avg": round(kernel_ms_max, 4),
@@ -291,7 +369,11 @@ def main() -> int:
                 "flop_per_cast": flop_per_cast,
                 "casts_per_launch": casts_this_rank,
                 "note": "no MFMA and not HBM-bound: the scene is 6.75 KB, the binding roof is FP32 vector issue "
-                        "(SURVEY §8d); hbm below is the algorithmic-bytes view the north_star asks for",
+                        "(SURVEY §8d); hbm below is the algorithmic-bytes view the north_star asks for. `achieved` counts "
+                        "ALGORITHMIC flop — casts x (T x 77 + S x 28), as if every cast ran every primitive test — i.e. an "
+                        "upper bound on useful work: the kernel's conservative rejections skip more than half of it, and "
+                        "the path may not use FMA (parity). Executed VALU work is in executed_valu (from SQ_INSTS_VALU, "
+                        "profiles/)",
                 "hbm": {
                     "achieved": round(alg_hbm_bytes / (kernel_ms_max * 1e-3) / 1e9, 3),
                     "peak": PEAK_HBM_GBS,
@@ -304,14 +386,28 @@ def main() -> int:
         if not args.no_cpu_baseline and world_size == 1:
             gpu_frame = full.cpu().numpy() if full is not None else None
             line["cpu_baseline"] = cpu_baseline(desc, camera, W, H, D, args.cpu_threads, gpu_frame)
-        if not args.no_stochastic and world_size == 1:
-            line["stochastic_pass"] = stochastic_pass(scene, camera, W, H, D, world_desc=None if args.no_cpu_baseline else desc, cpu_threads=args.cpu_threads)
+    # the other render loop (configs[3]), on every rank: after the headline's timed region, with its own barriers
+    stochastic = None
+    if not args.no_stochastic:
+        stochastic = stochastic_pass(scene, camera, W, H, D, rank, world_size, distributed,
+                                     world_desc=None if args.no_cpu_baseline else desc, cpu_threads=args.cpu_threads)
+    status = 0
+    if rank == 0:
+        if stochastic is not None:
+            line["stochastic_pass"] = stochastic
         print(json.dumps(line), flush=True)
+        # a fast frame that differs from the reference algorithm's is not a result: fail loudly
+        if line.get("cpu_baseline", {}).get("gpu_frame_bit_identical_to_cpu") is False:
+            sys.stderr.write("bench.py: the GPU frame differs from the CPU oracle's\n")
+            status = 1
+        if (stochastic or {}).get("cpu_baseline", {}).get("gpu_epoch_bit_identical_to_cpu") is False:
+            sys.stderr.write("bench.py: the GPU's depth-of-field epoch differs from the CPU oracle's\n")
+            status = 1
 
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return status
 
 
 if __name__ == "__main__":

@@ -126,7 +126,7 @@ AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
     "rt_get_variant", "rt_set_eviction", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
-    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_post_process_device", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
+    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_post_process_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",

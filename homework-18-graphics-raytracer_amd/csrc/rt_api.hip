@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -57,22 +58,24 @@ struct rt_scene {
     std::map<hipStream_t, Workspace> workspaces;
 };
 
-static int g_evict_threshold = -1, g_evict_min_iter = -1;
-static int g_wf_nodes_per_pixel = -1;
-static const uint32_t *g_diag_tile_order = nullptr;
+/* Process-wide settings (rt_set_*): read by render calls on any thread, so they are atomics.  A value < 0 means "not set
+ * yet": the first reader resolves it from the environment (two threads doing that at once compute the same value). */
+static std::atomic<int> g_evict_threshold{-1}, g_evict_min_iter{-1};
+static std::atomic<int> g_wf_nodes_per_pixel{-1};
+static std::atomic<const uint32_t *> g_diag_tile_order{nullptr};
 #ifndef RT_DIST_SPLIT_DEFAULT
 #define RT_DIST_SPLIT_DEFAULT 1
 #endif
-static int g_dist_split = -1; /* -1: RT_AMD_DIST_SPLIT or the default */
-extern "C" int rt_set_distributed_split(int on) { g_dist_split = on < 0 ? -1 : (on ? 1 : 0); return 0; }
-extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order = static_cast<const uint32_t *>(device_ptr); }
+static std::atomic<int> g_dist_split{-1}; /* -1: RT_AMD_DIST_SPLIT or the default */
+extern "C" int rt_set_distributed_split(int on) { g_dist_split.store(on < 0 ? -1 : (on ? 1 : 0)); return 0; }
+extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order.store(static_cast<const uint32_t *>(device_ptr)); }
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
 #endif
 
 static thread_local std::string g_error;
-static int g_variant = -1;
+static std::atomic<int> g_variant{-1};
 
 static int fail(int code, const std::string &msg) {
     g_error = msg;
@@ -91,17 +94,35 @@ static int fail_hip(const char *what, hipError_t e) {
     } while (0)
 
 static int current_variant() {
-    if (g_variant < 0) {
-        const char *v = getenv("RT_AMD_VARIANT");
-        g_variant = (v && *v) ? atoi(v) : RT_VARIANT_DEFAULT;
-        if (g_variant < 0 || g_variant > RT_VARIANT_MAX) g_variant = RT_VARIANT_DEFAULT;
+    int v = g_variant.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("RT_AMD_VARIANT");
+        v = (e && *e) ? atoi(e) : RT_VARIANT_DEFAULT;
+        if (v < 0 || v > RT_VARIANT_MAX) v = RT_VARIANT_DEFAULT;
+        g_variant.store(v, std::memory_order_relaxed);
     }
-    return g_variant;
+    return v;
+}
+static int current_wf_budget() {
+    int v = g_wf_nodes_per_pixel.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("RT_AMD_WF_NODES_PER_PIXEL");
+        v = (e && *e) ? atoi(e) : 6; /* the reference scene needs 3.4 at depth 8 */
+        if (v < 1 || v > 4096) v = 6;
+        g_wf_nodes_per_pixel.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 static bool frame_ok(const rt_frame *f) {
     return f && f->width > 0 && f->height > 0 && f->y_step >= 1 && f->x0 < f->x1 && f->y0 < f->y1 && f->x1 <= f->width &&
            f->y1 <= f->height;
+}
+/* the kernels and launchers index a tile's pixels with 32-bit arithmetic: a tile of 2^32 pixels or more is refused
+ * rather than wrapped (65536 x 65536 would wrap to 0 and "render" nothing) */
+static bool frame_fits(const rt_frame *f) {
+    const uint64_t rows = ((uint64_t)f->y1 - f->y0 + f->y_step - 1) / f->y_step;
+    return rows * (uint64_t)(f->x1 - f->x0) < (1ull << 32) - 64u;
 }
 
 extern "C" {
@@ -124,35 +145,40 @@ int rt_set_device(int device) {
 
 int rt_set_variant(int variant) {
     if (variant < 0 || variant > RT_VARIANT_MAX) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: variant out of range");
-    g_variant = variant;
+    g_variant.store(variant);
     return RT_OK;
 }
 int rt_get_variant(void) { return current_variant(); }
 
 int rt_set_wavefront_budget(unsigned nodes_per_pixel) {
     if (nodes_per_pixel < 1u || nodes_per_pixel > 4096u) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_wavefront_budget: 1..4096 nodes per pixel");
-    g_wf_nodes_per_pixel = (int)nodes_per_pixel;
+    g_wf_nodes_per_pixel.store((int)nodes_per_pixel);
     return RT_OK;
 }
 
 /* ---- profiling of the dominant kernel ----
  * bench.py's roofline needs the duration of the render kernel alone (a call may also launch the small probe
  * kernel).  When enabled, every rt_render_whitted call records a HIP event pair on the launch stream right
- * around that kernel; rt_profile_read() synchronises and sums the elapsed times. */
+ * around that kernel; rt_profile_read() synchronises and sums the elapsed times.
+ * Thread safety: the event list is under a mutex; the pair a call is recording into travels in thread-local state of the
+ * calling thread (rt_kernels.hip), so render calls on several host threads do not see each other's events. */
+static std::mutex g_prof_mutex;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static size_t g_prof_used = 0;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 
 int rt_profile_enable(int on) {
-    g_prof_on = on != 0;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on.store(on != 0);
     g_prof_used = 0;
-    if (!g_prof_on) rt::set_main_kernel_events(nullptr, nullptr);
+    rt::set_main_kernel_events(nullptr, nullptr);
     return RT_OK;
 }
 
 int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches) {
     if (!kernel_ms_sum || !n_launches) return fail(RT_ERR_INVALID_ARGUMENT, "rt_profile_read: null argument");
     RT_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     double sum = 0.0;
     for (size_t i = 0; i < g_prof_used; ++i) {
         float ms = 0.0f;
@@ -167,8 +193,8 @@ int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches) {
 
 int rt_set_eviction(int threshold, int min_iterations) {
     if (threshold < 0 || threshold > 63 || min_iterations < 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_eviction: threshold 0..63, min_iterations >= 0");
-    g_evict_threshold = threshold;
-    g_evict_min_iter = min_iterations;
+    g_evict_threshold.store(threshold);
+    g_evict_min_iter.store(min_iterations);
     return RT_OK;
 }
 
@@ -445,7 +471,9 @@ int rt_scene_destroy(rt_scene *scene) {
 static int make_kernel_frame(const rt_camera *camera, const rt_frame *frame, rt::KernelFrame *kf) {
     if (!camera) return fail(RT_ERR_INVALID_ARGUMENT, "render: null camera");
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "render: bad frame (need 0 <= x0 < x1 <= width, 0 <= y0 < y1 <= height, y_step >= 1)");
+    if (!frame_fits(frame)) return fail(RT_ERR_UNSUPPORTED, "render: tile of 2^32 pixels or more (render it as several tiles)");
     if (frame->max_depth > RT_MAX_DEPTH) return fail(RT_ERR_UNSUPPORTED, "render: max_depth above RT_MAX_DEPTH");
+    /* max_depth < 0 is valid and renders as 0: TraceState.depth is an i32 tested with `depth <= 0` (main.rs:488, 669) */
     using rt::V3;
     /* Camera::shoot, main.rs:85-92: the ray-independent part */
     const V3 toward = rt::normalize(rt::v3p(camera->toward));
@@ -484,25 +512,25 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     /* the persistent-wavefront path packs the ray's face mode and the depth left next to a 21-bit primitive id */
     if ((variant & RT_VARIANT_PWF) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 21)) variant &= ~RT_VARIANT_PWF;
     if ((variant & RT_VARIANT_PWF) && (scene->ks.n_lights >= (1u << 15) || scene->ks.n_materials >= (1u << 16))) variant &= ~RT_VARIANT_PWF;
-    if (g_wf_nodes_per_pixel < 0) {
-        const char *v = getenv("RT_AMD_WF_NODES_PER_PIXEL");
-        g_wf_nodes_per_pixel = (v && *v) ? atoi(v) : 6; /* the reference scene needs 3.4 at depth 8 */
-        if (g_wf_nodes_per_pixel < 1 || g_wf_nodes_per_pixel > 4096) g_wf_nodes_per_pixel = 6;
-    }
+    const int wf_budget = current_wf_budget();
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);
     uint32_t pw_groups = 0, pw_band_rows = 0;
-    if (g_evict_threshold < 0) {
+    int evict_threshold = g_evict_threshold.load(), evict_min_iter = g_evict_min_iter.load();
+    if (evict_threshold < 0) {
         const char *v = getenv("RT_AMD_EVICT_THRESHOLD");
-        g_evict_threshold = (v && *v) ? atoi(v) : 16;
-        if (g_evict_threshold < 0 || g_evict_threshold > 63) g_evict_threshold = 16;
+        evict_threshold = (v && *v) ? atoi(v) : 16;
+        if (evict_threshold < 0 || evict_threshold > 63) evict_threshold = 16;
         const char *m = getenv("RT_AMD_EVICT_MIN_ITER");
-        g_evict_min_iter = (m && *m) ? atoi(m) : 4;
+        evict_min_iter = (m && *m) ? atoi(m) : 4;
+        if (evict_min_iter < 0) evict_min_iter = 4;
+        g_evict_threshold.store(evict_threshold);
+        g_evict_min_iter.store(evict_min_iter);
     }
     rt::KernelQueues qs;
     memset(&qs, 0, sizeof qs);
-    qs.evict_threshold = (uint32_t)g_evict_threshold;
-    qs.evict_min_iterations = (uint32_t)g_evict_min_iter;
+    qs.evict_threshold = (uint32_t)evict_threshold;
+    qs.evict_min_iterations = (uint32_t)evict_min_iter;
     {
         rt_scene *mut = const_cast<rt_scene *>(scene); /* workspaces are the only mutable part of a scene */
         std::lock_guard<std::mutex> lock(mut->ws_mutex);
@@ -543,7 +571,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             uint64_t groups = (pixels + 63u) / 64u; /* a workgroup fetches one to eight tiles at a time */
             if (groups > scene->pwf_workgroups) groups = scene->pwf_workgroups;
             if (groups < 1) groups = 1;
-            const uint64_t max_pixels = (ring_max - 1024u) * groups / (uint64_t)g_wf_nodes_per_pixel;
+            const uint64_t max_pixels = (ring_max - 1024u) * groups / (uint64_t)wf_budget;
             pw_band_rows = kf.rows;
             if (pixels > max_pixels) {
                 const uint64_t n_bands = (pixels + max_pixels - 1) / max_pixels;
@@ -552,10 +580,10 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 pw_band_rows = (uint32_t)(rows < kf.rows ? rows : kf.rows);
             }
             const uint64_t band_pixels = (uint64_t)kf.cols * pw_band_rows;
-            const uint64_t want = (band_pixels * (uint64_t)g_wf_nodes_per_pixel + groups - 1) / groups; /* nodes per arena */
+            const uint64_t want = (band_pixels * (uint64_t)wf_budget + groups - 1) / groups; /* nodes per arena */
             /* tiles are handed out dynamically, so a workgroup may end up with several times the average: arenas have a
              * floor of 8192 ring slots (1.5 MB) however small the frame (budgets below 4 waive it: tests of the fallback) */
-            uint64_t ring = g_wf_nodes_per_pixel >= 4 ? 8192 : 2048;
+            uint64_t ring = wf_budget >= 4 ? 8192 : 2048;
             while (ring < want + 1024u && ring < ring_max) ring <<= 1;
             pw.ring_cap = (uint32_t)ring;
             /* (the budget sizes the rings; an arena may use all of its ring's worth of nodes: tiles are handed out
@@ -577,7 +605,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 }
             }
             if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
-            pw.tile_order = g_diag_tile_order;
+            pw.tile_order = g_diag_tile_order.load();
             pw.global = static_cast<uint32_t *>(ws.d_pwf);
             pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 128);
             static_assert(sizeof(rt::KernelFrame) <= 128, "the frame description must fit its slot of the workspace header");
@@ -591,7 +619,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         qs.timeline = g_diag_timeline;
 #endif
     }
-    if (g_prof_on) {
+    if (g_prof_on.load()) {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
         if (g_prof_used == g_prof_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             RT_HIP(hipEventCreate(&a));
@@ -600,6 +629,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         }
         rt::set_main_kernel_events(g_prof_events[g_prof_used].first, g_prof_events[g_prof_used].second);
         g_prof_used += 1;
+    } else {
+        rt::set_main_kernel_events(nullptr, nullptr);
     }
     hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
     if (e == hipSuccess && (variant & RT_VARIANT_PWF)) {
@@ -684,6 +715,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (!out_rng) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_create: null argument");
     *out_rng = nullptr;
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_rng_create: bad frame");
+    if (!frame_fits(frame)) return fail(RT_ERR_UNSUPPORTED, "rt_rng_create: tile of 2^32 pixels or more");
     rt_rng *r = new (std::nothrow) rt_rng();
     if (!r) return fail(RT_ERR_OUT_OF_MEMORY, "rt_rng_create: host allocation failed");
     r->cols = frame->x1 - frame->x0;
@@ -791,7 +823,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.work_queue = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
-    int split = g_dist_split;
+    int split = g_dist_split.load();
     if (split < 0) {
         const char *v = getenv("RT_AMD_DIST_SPLIT");
         split = v && *v ? (*v != '0') : RT_DIST_SPLIT_DEFAULT;
@@ -932,17 +964,38 @@ struct PostWs {
     size_t n = 0;
     uint32_t *d_state = nullptr;
 };
+/* keyed by (device, stream): the default stream is nullptr on every device, and a buffer allocated on one device must
+ * not serve a launch on another.  Grow-only; rt_post_release() frees the buffers of the current device. */
 static std::mutex g_post_mutex;
-static std::map<hipStream_t, PostWs> g_post_ws;
+static std::map<std::pair<int, hipStream_t>, PostWs> g_post_ws;
+
+int rt_post_release(void) {
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
+    RT_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_post_mutex);
+    for (auto it = g_post_ws.begin(); it != g_post_ws.end();) {
+        if (it->first.first == device) {
+            if (it->second.d_keys) (void)hipFree(it->second.d_keys);
+            if (it->second.d_state) (void)hipFree(it->second.d_state);
+            it = g_post_ws.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return RT_OK;
+}
 
 int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void *hip_stream) {
     if (!d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_process_device: null argument");
     if (n_pixels == 0) return RT_OK;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t *keys = nullptr, *state = nullptr;
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
     {
         std::lock_guard<std::mutex> lock(g_post_mutex);
-        PostWs &ws = g_post_ws[stream];
+        PostWs &ws = g_post_ws[std::make_pair(device, stream)];
         if (!ws.d_state) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_state), 260 * sizeof(uint32_t)));
         if (n_pixels > ws.n) {
             if (ws.d_keys) (void)hipFree(ws.d_keys);

@@ -758,8 +758,9 @@ static hipError_t launch_mode(const KernelScene &sc, const KernelFrame &fr, floa
 }
 
 /* optional HIP events recorded on the launch stream right around the dominant (render) kernel of a call */
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static bool g_ev_muted = false; /* set around launches that are not "the" render kernel (the wavefront path's fallback) */
+/* thread-local: set by a render call on its own host thread and read by the launchers it calls on that thread */
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local bool g_ev_muted = false; /* set around launches that are not "the" render kernel (the wavefront path's fallback) */
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 void mute_main_kernel_events(bool muted) { g_ev_muted = muted; }
 void record_main_kernel_event(int which, hipStream_t stream) {

@@ -14,6 +14,14 @@
  * (the reference's convention is panic!/unwrap — src/main.rs:767-775,785 —
  * which cannot cross a C ABI).  rt_last_error() returns a thread-local message
  * for the last failing call.
+ *
+ * Threading (the reference shares `&World` immutably between rayon threads and
+ * gives each pixel exclusive `&mut` access to its RNG, main.rs:1096, 1131):
+ * an rt_scene is immutable and may be rendered from several host threads at
+ * once, each on its own HIP stream (per-(scene, stream) workspaces are created
+ * under a lock; the rt_set_* settings are atomics; the profiling hooks keep the
+ * event pair of a call in thread-local state).  Calls on ONE stream, and calls
+ * on one rt_rng, must be serialised by the caller.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -135,10 +143,12 @@ typedef struct rt_camera {
  * Rendered pixels: x in [x0,x1), y in {y0, y0+y_step, ...} < y1.
  * Output is compact: out[((row * (x1-x0)) + (x - x0)) * 3 + c], row = (y-y0)/y_step.
  * With x0=y0=0, x1=width, y1=height, y_step=1 that is the reference's
- * row-major [y*width + x] (image.rs:35-47). */
+ * row-major [y*width + x] (image.rs:35-47).  A tile must hold fewer than 2^32
+ * pixels (RT_ERR_UNSUPPORTED otherwise: render it as several tiles). */
 typedef struct rt_frame {
     uint32_t width, height;
-    int32_t  max_depth;      /* TraceState.depth at the root (main.rs:1098) */
+    int32_t  max_depth;      /* TraceState.depth at the root (main.rs:1098); an i32 tested with `depth <= 0`
+                              * (main.rs:488, 669), so a negative value renders like 0, as in the reference */
     uint32_t x0, y0, x1, y1;
     uint32_t y_step;         /* >= 1 */
 } rt_frame;
@@ -233,6 +243,9 @@ int rt_render_distributed_host(const rt_scene *scene, const rt_camera *camera, c
  * the image was left untouched (no normal luma, or percentile <= f32::EPSILON).  Bit-identical to
  * rt_post_process in librt_host.so.  Stream-ordered. */
 int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void *hip_stream);
+/* rt_post_process_device keeps a grow-only scratch buffer per (device, stream); this frees those of the current device
+ * (synchronises it first). */
+int rt_post_release(void);
 /* Image::<Srgb<u8>>::convert_from (src/image.rs:55-66): linear f32 -> sRGB-encoded u8, n_values = 3*pixels. */
 int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream);
 /* PhotonAccumulator (src/photon.rs:9-34; unused by the reference's main()) on the device, bit-identical to

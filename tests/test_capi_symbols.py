@@ -45,6 +45,10 @@ def test_argument_validation_returns_status():
     good = rt.Frame.rows_of_rank(1920, 1080, 8, 3, 8)
     assert lib.rt_frame_rows(C.byref(good)) == 135 and lib.rt_frame_pixels(C.byref(good)) == 135 * 1920
     assert lib.rt_set_variant(99) == -1 and lib.rt_set_eviction(64, 0) == -1
+    # a tile of 2^32 pixels or more is refused, not wrapped (checked before any device work)
+    huge = rt.Frame.full(65536, 65536, 5)
+    h = C.c_void_p()
+    assert lib.rt_rng_create(C.byref(huge), C.byref(h)) == -5 and b"2^32" in lib.rt_last_error()
     assert lib.rt_rng_create(None, None) == -1 and lib.rt_render_distributed(None, None, None, 3.0, 0.04, None, 1, None, None, None, None, None) == -1
 
 

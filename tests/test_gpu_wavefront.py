@@ -176,6 +176,51 @@ def test_two_streams_render_concurrently_with_their_own_workspaces(ref):
             assert torch.equal(outs[k].view(torch.int32), want[k].view(torch.int32))
 
 
+def test_two_host_threads_render_concurrently_with_profiling_on(ref):
+    """rt_render_whitted from two HOST threads, each on its own stream, with the profiling hooks enabled: the settings
+    are atomics, the workspaces are created under the scene's lock and a call's event pair is thread-local, so both
+    threads get bit-identical frames and every launch is timed exactly once (include/rt_amd.h "Threading")."""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    world, cam, scene = ref
+    lib = _capi.amd_lib()
+    frames = [rt.Frame.full(320, 240, 6), rt.Frame.full(257, 199, 8)]
+    want = [rt.render_whitted(scene, cam, f).clone() for f in frames]
+    torch.cuda.synchronize()
+    reps, errors = 12, []
+    outs = [[torch.zeros_like(want[k]) for _ in range(reps)] for k in range(2)]
+    _capi.check(lib.rt_profile_enable(1))
+    start = threading.Barrier(2)
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            start.wait()
+            for r in range(reps):
+                rt.render_whitted(scene, cam, frames[k], out=outs[k][r], stream=stream)
+            stream.synchronize()
+        except Exception as exc:  # surfaced below: an exception in a thread must fail the test
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ms, n = C.c_double(0.0), C.c_uint(0)
+    _capi.check(lib.rt_profile_read(C.byref(ms), C.byref(n)))
+    _capi.check(lib.rt_profile_enable(0))
+    assert not errors, errors
+    assert n.value == 2 * reps and ms.value > 0.0
+    for k in range(2):
+        for r in range(reps):
+            assert torch.equal(outs[k][r].view(torch.int32), want[k].view(torch.int32)), (k, r)
+
+
 def test_no_memory_for_the_arenas_means_the_per_pixel_kernel(ref):
     """If the arenas cannot be allocated the frame is rendered by the per-pixel kernel in the same call (the hook makes
     the allocation fail; a scene of its own, because the workspace is kept per scene and stream)."""
