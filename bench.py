@@ -111,8 +111,8 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
     frame = rtdist.shard_frame(width, height, depth, rank, world_size)
     accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-    warm = rt.Rng(frame)  # untimed: sizes the workspace, loads the kernels
-    rt.render_distributed(scene, camera, frame, warm, 8, accum=accum)
+    warm = rt.Rng(frame)  # untimed: loads the kernels and sizes the per-stream workspace for calls of this many epochs
+    rt.render_distributed(scene, camera, frame, warm, epochs, accum=accum)
     torch.cuda.synchronize()
     warm.close()
     del warm

@@ -100,6 +100,18 @@ class World:
     def push_light(self, light: Light) -> None:
         _capi.check_host(_capi.host_lib().rt_world_push_light(self._h, C.byref(light)))
 
+    def save_scene(self, path: str, camera: Optional[Camera] = None) -> None:
+        """Write the world (and optionally a camera) as a flat scene file: rt_world_save_scene, include/rt_host.h."""
+        _capi.check_host(_capi.host_lib().rt_world_save_scene(self._h, C.byref(camera) if camera is not None else None, str(path).encode()))
+
+    @classmethod
+    def load_scene(cls, path: str):
+        """Read a scene file: returns (World, Camera or None).  rt_world_load_scene, include/rt_host.h."""
+        w = cls()
+        cam, has = Camera(), C.c_int(0)
+        _capi.check_host(_capi.host_lib().rt_world_load_scene(w._h, str(path).encode(), C.byref(cam), C.byref(has)))
+        return w, (cam if has.value else None)
+
     def desc(self) -> SceneDesc:
         d = SceneDesc()
         _capi.host_lib().rt_world_desc(self._h, C.byref(d))

@@ -131,7 +131,7 @@ AMD_SYMBOLS = [
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
     "rt_world_push_light", "rt_world_push_flat_triangle", "rt_world_push_square", "rt_world_load_obj",
-    "rt_world_build_reference_scene", "rt_reference_camera", "rt_world_desc", "rt_frame_full", "rt_post_process",
+    "rt_world_build_reference_scene", "rt_world_save_scene", "rt_world_load_scene", "rt_reference_camera", "rt_world_desc", "rt_frame_full", "rt_post_process",
     "rt_encode_srgb8", "rt_accumulate", "rt_accumulator_resolve", "rt_write_png", "rt_host_last_error",
 ]
 
@@ -161,6 +161,8 @@ def host_lib() -> C.CDLL:
         lib.rt_world_push_square.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.rt_world_load_obj.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_float, C.POINTER(C.c_float)]
         lib.rt_world_build_reference_scene.argtypes = [C.c_void_p, C.c_char_p]
+        lib.rt_world_save_scene.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_char_p]
+        lib.rt_world_load_scene.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Camera), C.POINTER(C.c_int)]
         lib.rt_reference_camera.argtypes = [C.POINTER(Camera)]
         lib.rt_reference_camera.restype = None
         lib.rt_world_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]

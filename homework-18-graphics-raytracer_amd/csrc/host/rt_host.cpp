@@ -354,6 +354,114 @@ void rt_world_desc(const rt_world *world, rt_scene_desc *out) {
     out->lights = world->lights.data();       out->n_lights = (uint32_t)world->lights.size();
 }
 
+/* ---- the scene as a data format -----------------------------------
+ * One flat little-endian file: a 128-byte header, then the four arrays of rt_scene_desc exactly as they sit in memory
+ * (rt_material[], rt_triangle[], rt_sphere[], rt_light[]: include/rt_amd.h).  Array order is kept (ties and the light
+ * sum depend on it).  The header records each record's size so that a reader built against another ABI revision
+ * refuses the file instead of misreading it. */
+struct SceneFileHeader {
+    char magic[8];          /* "RTSCENE\0" */
+    uint32_t version;       /* 1 */
+    uint32_t endian;        /* 0x01020304 as written by the producer */
+    uint32_t n_materials, n_triangles, n_spheres, n_lights;
+    uint32_t sizeof_material, sizeof_triangle, sizeof_sphere, sizeof_light;
+    uint32_t has_camera;
+    rt_camera camera;       /* 11 f32 */
+    uint32_t reserved[8];
+};
+static_assert(sizeof(SceneFileHeader) == 128, "scene file header");
+static const char SCENE_MAGIC[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', 0};
+
+int rt_world_save_scene(const rt_world *world, const rt_camera *camera, const char *path) {
+    if (!world || !path) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_save_scene: null argument");
+    SceneFileHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, SCENE_MAGIC, 8);
+    h.version = 1u;
+    h.endian = 0x01020304u;
+    h.n_materials = (uint32_t)world->objects.size();
+    h.n_triangles = (uint32_t)world->triangles.size();
+    h.n_spheres = (uint32_t)world->spheres.size();
+    h.n_lights = (uint32_t)world->lights.size();
+    h.sizeof_material = (uint32_t)sizeof(rt_material);
+    h.sizeof_triangle = (uint32_t)sizeof(rt_triangle);
+    h.sizeof_sphere = (uint32_t)sizeof(rt_sphere);
+    h.sizeof_light = (uint32_t)sizeof(rt_light);
+    if (camera) { h.has_camera = 1u; h.camera = *camera; }
+    const std::string tmp = std::string(path) + ".tmp"; /* written beside the target, then renamed over it (as write_to_file) */
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_world_save_scene: cannot open ") + tmp + ": " + strerror(errno));
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    auto put = [&](const void *data, size_t size, size_t n) { if (ok && n) ok = fwrite(data, size, n, f) == n; };
+    put(world->objects.data(), sizeof(rt_material), world->objects.size());
+    put(world->triangles.data(), sizeof(rt_triangle), world->triangles.size());
+    put(world->spheres.data(), sizeof(rt_sphere), world->spheres.size());
+    put(world->lights.data(), sizeof(rt_light), world->lights.size());
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        remove(tmp.c_str());
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_world_save_scene: write failed for ") + path);
+    }
+    return RT_OK;
+}
+
+int rt_world_load_scene(rt_world *world, const char *path, rt_camera *out_camera, int *out_has_camera) {
+    if (!world || !path) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_load_scene: null argument");
+    if (out_has_camera) *out_has_camera = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_world_load_scene: cannot open ") + path + ": " + strerror(errno));
+    SceneFileHeader h;
+    auto bail = [&](const char *why) { fclose(f); return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_world_load_scene: ") + why + " in " + path); };
+    if (fread(&h, sizeof h, 1, f) != 1) return bail("short header");
+    if (memcmp(h.magic, SCENE_MAGIC, 8) != 0) return bail("not a scene file (bad magic)");
+    if (h.endian != 0x01020304u) return bail("written on a machine of the other byte order");
+    if (h.version != 1u) { fclose(f); return fail(RT_ERR_UNSUPPORTED, std::string("rt_world_load_scene: unknown version in ") + path); }
+    if (h.sizeof_material != sizeof(rt_material) || h.sizeof_triangle != sizeof(rt_triangle) || h.sizeof_sphere != sizeof(rt_sphere) ||
+        h.sizeof_light != sizeof(rt_light)) {
+        fclose(f);
+        return fail(RT_ERR_UNSUPPORTED, std::string("rt_world_load_scene: record sizes of another ABI revision in ") + path);
+    }
+    const uint64_t body = (uint64_t)h.n_materials * sizeof(rt_material) + (uint64_t)h.n_triangles * sizeof(rt_triangle) +
+                          (uint64_t)h.n_spheres * sizeof(rt_sphere) + (uint64_t)h.n_lights * sizeof(rt_light);
+    if (fseek(f, 0, SEEK_END) != 0) return bail("cannot seek");
+    const long end = ftell(f);
+    if (end < 0 || (uint64_t)end != sizeof h + body) return bail("file size does not match the counts in its header");
+    if (fseek(f, (long)sizeof h, SEEK_SET) != 0) return bail("cannot seek");
+    rt_world fresh; /* the world is replaced only when the whole file is good */
+    bool ok = true;
+    try {
+        fresh.objects.resize(h.n_materials);
+        fresh.triangles.resize(h.n_triangles);
+        fresh.spheres.resize(h.n_spheres);
+        fresh.lights.resize(h.n_lights);
+    } catch (...) {
+        fclose(f);
+        return fail(RT_ERR_OUT_OF_MEMORY, "rt_world_load_scene: out of memory");
+    }
+    auto get = [&](void *data, size_t size, size_t n) { if (ok && n) ok = fread(data, size, n, f) == n; };
+    get(fresh.objects.data(), sizeof(rt_material), fresh.objects.size());
+    get(fresh.triangles.data(), sizeof(rt_triangle), fresh.triangles.size());
+    get(fresh.spheres.data(), sizeof(rt_sphere), fresh.spheres.size());
+    get(fresh.lights.data(), sizeof(rt_light), fresh.lights.size());
+    if (!ok) return bail("short read");
+    fclose(f);
+    for (const rt_material &m : fresh.objects)
+        if (m.diffuse_fn > RT_DIFFUSE_STRIPE_SUM || m.normal_fn > RT_NORMAL_WAVE_U) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_load_scene: unknown material function");
+    for (const rt_triangle &t : fresh.triangles)
+        if (t.object_index >= h.n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_load_scene: triangle object index out of range");
+    for (const rt_sphere &sp : fresh.spheres)
+        if (sp.object_index >= h.n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_load_scene: sphere object index out of range");
+    for (const rt_light &l : fresh.lights)
+        if (l.kind > RT_LIGHT_POINT) return fail(RT_ERR_INVALID_ARGUMENT, "rt_world_load_scene: unknown light kind");
+    world->objects.swap(fresh.objects);
+    world->triangles.swap(fresh.triangles);
+    world->spheres.swap(fresh.spheres);
+    world->lights.swap(fresh.lights);
+    if (h.has_camera && out_camera) *out_camera = h.camera;
+    if (out_has_camera) *out_has_camera = h.has_camera ? 1 : 0;
+    return RT_OK;
+}
+
 void rt_frame_full(uint32_t width, uint32_t height, int32_t max_depth, rt_frame *out) {
     if (!out) return;
     out->width = width; out->height = height; out->max_depth = max_depth;

@@ -3,13 +3,15 @@
  * with the two rayon render loops replaced by calls across the C ABI.
  *
  *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png] [--epochs N]
- *             [--focus F] [--blur B]
+ *             [--focus F] [--blur B] [--scene in.rtscene] [--save-scene out.rtscene]
  *
  * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).  --epochs N (default 0; the
  * reference: 100, main.rs:1129) continues as main() does: N epochs of the depth-of-field pass (shoot_focus(focus, blur),
  * defaults 3.0 / 0.04 = main.rs:1147-1148; depth 5) added to the normalised image, post_process and a rewrite of the PNG
  * after every epoch (main.rs:1129-1174).  `--epochs 7` reproduces report/out.png, `--epochs 7 --blur 0.02`
  * report/out_small_blur.png (tests/test_gpu_reference_pins.py).
+ * --scene renders a scene file (rt_world_load_scene; its camera if it carries one, else main()'s) instead of the literal
+ * scene; --save-scene writes the scene in use (with the camera) as such a file before rendering.
  * Host keeps: scene build + OBJ import, post_process, sRGB/u8 encode, PNG write.
  */
 #include <chrono>
@@ -26,6 +28,7 @@ int main(int argc, char **argv) {
     int32_t depth = 5;
     const char *obj = "dodecahedron.obj";
     const char *out = "./out.png";
+    const char *scene_in = nullptr, *scene_out = nullptr;
     int epochs = 0;
     float focus = 3.0f, blur = 0.04f; /* main.rs:1147-1148 */
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -35,19 +38,26 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--obj")) obj = argv[i + 1];
         else if (!strcmp(argv[i], "--out")) out = argv[i + 1];
         else if (!strcmp(argv[i], "--epochs")) epochs = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--scene")) scene_in = argv[i + 1];
+        else if (!strcmp(argv[i], "--save-scene")) scene_out = argv[i + 1];
         else if (!strcmp(argv[i], "--focus")) focus = strtof(argv[i + 1], nullptr);
         else if (!strcmp(argv[i], "--blur")) blur = strtof(argv[i + 1], nullptr);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     rt_world *world = rt_world_new();
-    if (!world || rt_world_build_reference_scene(world, obj) != RT_OK) {
+    rt_camera camera;
+    rt_reference_camera(&camera);
+    int file_has_camera = 0;
+    if (!world || (scene_in ? rt_world_load_scene(world, scene_in, &camera, &file_has_camera) : rt_world_build_reference_scene(world, obj)) != RT_OK) {
         fprintf(stderr, "scene build failed: %s\n", rt_host_last_error());
+        return 1;
+    }
+    if (scene_out && rt_world_save_scene(world, &camera, scene_out) != RT_OK) {
+        fprintf(stderr, "rt_world_save_scene failed: %s\n", rt_host_last_error());
         return 1;
     }
     rt_scene_desc desc;
     rt_world_desc(world, &desc);
-    rt_camera camera;
-    rt_reference_camera(&camera);
     rt_frame frame;
     rt_frame_full(width, height, depth, &frame);
 

@@ -11,6 +11,7 @@
  *   triangle() / square() flat-normal helpers    src/main.rs:730-746
  *   load_obj                                     src/main.rs:778-807
  *   the literal scene and camera of main()       src/main.rs:810-1083
+ *   (the same scene as a file: rt_world_save_scene / rt_world_load_scene)
  *   post_process                                 src/main.rs:748-762
  *   Image::<Srgb<u8>>::convert_from              src/image.rs:55-66
  *   write_to_file (tmp file + rename)            src/main.rs:764-776
@@ -61,6 +62,15 @@ void rt_reference_camera(rt_camera *out);
 
 /* View of the world's arrays (valid until the next push / free). */
 void rt_world_desc(const rt_world *world, rt_scene_desc *out);
+
+/* The scene as a data format: one flat little-endian file — a 128-byte header ("RTSCENE", version,
+ * counts, record sizes, optionally the camera) followed by the arrays of rt_scene_desc exactly as declared in rt_amd.h,
+ * in the order materials, triangles, spheres, lights; array order is preserved (it is semantically significant).
+ * rt_world_save_scene writes "<path>.tmp" and renames it over path.  rt_world_load_scene REPLACES the world's contents
+ * (only if the whole file is valid: magic, version, byte order, record sizes, file length, index and enum ranges);
+ * *out_camera is filled and *out_has_camera set when the file carries a camera (both may be NULL). */
+int rt_world_save_scene(const rt_world *world, const rt_camera *camera_or_null, const char *path);
+int rt_world_load_scene(rt_world *world, const char *path, rt_camera *out_camera, int *out_has_camera);
 
 /* Full-frame rt_frame helper: tile = whole image. */
 void rt_frame_full(uint32_t width, uint32_t height, int32_t max_depth, rt_frame *out);

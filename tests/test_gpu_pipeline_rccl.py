@@ -42,3 +42,45 @@ def test_pipelined_gather_over_rccl_single_rank():
             assert torch.equal(got[k].view(torch.int32), want.view(torch.int32)), f"frame {k}"
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_stochastic_pass_over_rccl_single_rank():
+    """configs[3]'s plumbing (bench.py's stochastic_pass for N > 1) on one rank: accumulate_epochs_sharded — the rank's
+    epochs on its row band, then the RCCL gather — against the oracle's sum of the same epochs, and the `y_step` bands
+    of a 3-way split (rendered here one after the other on the one GPU) against the full frame's pixels."""
+    import torch
+    import torch.distributed as dist
+
+    import _oracle
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        world = rt.reference_world(); cam = rt.reference_camera(); scene = rt.Scene(world)
+        w, h, depth, epochs = 160, 99, 5, 5
+
+        def render_epochs(frame):
+            rng = rt.Rng(frame)
+            acc = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+            rt.render_distributed(scene, cam, frame, rng, epochs, accum=acc)
+            return acc
+
+        full = rtdist.accumulate_epochs_sharded(render_epochs, w, h, depth, 0, 1)
+        torch.cuda.synchronize()
+        frame = rt.Frame.full(w, h, depth)
+        s_, v_, _ = _oracle.render_distributed(world.desc(), cam, frame, _oracle.rng_init(frame), epochs)
+        want = np.zeros((h, w, 3), dtype=np.float32)
+        for e in range(epochs):  # img[at] = img[at] + photon in epoch order (main.rs:1163-1167)
+            want += np.where(v_[e][..., None] != 0, s_[e], np.float32(0))
+        got = full.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # a pixel's stream is seeded by IMAGE coordinates: the bands of a 3-way split hold the same sums
+        for r in range(3):
+            band = render_epochs(rtdist.shard_frame(w, h, depth, r, 3)).cpu().numpy()
+            assert np.array_equal(band.view(np.uint32), want[r::3].view(np.uint32)), f"band {r}"
+    finally:
+        dist.destroy_process_group()

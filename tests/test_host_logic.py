@@ -110,3 +110,69 @@ def test_png_roundtrip(tmp_path):
     rt.write_to_file(str(p), img)
     assert not (tmp_path / "x.png.tmp").exists()
     assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img)
+
+
+# ---- the scene as a data format: rt_world_save_scene / rt_world_load_scene --------------------------------
+
+def _desc_bytes(d):
+    return (C.string_at(d.materials, d.n_materials * C.sizeof(_capi.Material)), C.string_at(d.triangles, d.n_triangles * C.sizeof(_capi.Triangle)),
+            C.string_at(d.spheres, d.n_spheres * C.sizeof(_capi.Sphere)), C.string_at(d.lights, d.n_lights * C.sizeof(_capi.Light)))
+
+
+def test_scene_file_round_trip_is_byte_exact_and_renders_identically(tmp_path):
+    world, cam = rt.reference_world(), rt.reference_camera()
+    path = tmp_path / "reference.rtscene"
+    world.save_scene(path, cam)
+    d = world.desc()
+    assert path.stat().st_size == 128 + sum(len(b) for b in _desc_bytes(d))
+    assert not (tmp_path / "reference.rtscene.tmp").exists()  # written beside the target, then renamed over it
+    loaded, cam2 = rt.World.load_scene(path)
+    assert cam2 is not None and bytes(cam2) == bytes(cam)
+    assert _desc_bytes(loaded.desc()) == _desc_bytes(d)  # array order kept: ties and the light sum depend on it
+    frame = rt.Frame.full(96, 72, 5)
+    a, ca = _oracle.render_whitted(d, cam, frame)
+    b, cb = _oracle.render_whitted(loaded.desc(), cam2, frame)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
+    # without a camera
+    world.save_scene(path)
+    _, none = rt.World.load_scene(path)
+    assert none is None
+
+
+def test_scene_file_validation(tmp_path):
+    world = rt.reference_world()
+    good = tmp_path / "good.rtscene"
+    world.save_scene(good, rt.reference_camera())
+    raw = bytearray(good.read_bytes())
+
+    def refuses(data, what):
+        bad = tmp_path / "bad.rtscene"
+        bad.write_bytes(bytes(data))
+        w = rt.World()
+        w.push_object(world.desc().materials[0])  # a failed load must leave the world as it was
+        try:
+            _capi.check_host(_capi.host_lib().rt_world_load_scene(w._h, str(bad).encode(), None, None))
+        except rt.RtError as e:
+            assert what in str(e), str(e)
+            assert w.desc().n_materials == 1
+            return
+        raise AssertionError(f"accepted a file with {what}")
+
+    refuses(b"PNG" + raw[3:], "magic")
+    refuses(raw[:-4], "file size")
+    refuses(raw + b"\0\0\0\0", "file size")
+    v = bytearray(raw); v[8] = 2
+    refuses(v, "version")
+    e = bytearray(raw); e[12:16] = e[12:16][::-1]
+    refuses(e, "byte order")
+    z = bytearray(raw); z[32] ^= 0xFF  # sizeof_material
+    refuses(z, "record sizes")
+    # the first triangle's object index out of range (triangles follow the 9 materials)
+    t = bytearray(raw); off = 128 + 9 * C.sizeof(_capi.Material); t[off:off + 4] = (99).to_bytes(4, "little")
+    refuses(t, "object index")
+    w = rt.World()
+    try:
+        _capi.check_host(_capi.host_lib().rt_world_load_scene(w._h, str(tmp_path / "missing.rtscene").encode(), None, None))
+        raise AssertionError("opened a missing file")
+    except rt.RtError as e:
+        assert "cannot open" in str(e)

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Scene-size sweep: the reference scene around a tessellated dodecahedron, through the scene FILE.
+
+    python tools/scene_sweep.py [--levels 0 1 2 3 4 5 6] [--variants 18 2 3] [--spherize] [--out profiles/r02_scene_sweep.jsonl]
+    python tools/scene_sweep.py --levels 4 --variants 18 --frames 3 --no-parity      # one configuration, e.g. under rocprofv3
+
+Per level k: tools/make_tessellated_obj.py writes the OBJ (36 * 4^k triangles), rt_world_build_reference_scene imports it
+through load_obj (main.rs:778-807) into the literal scene (28 other triangles, 4 spheres, 3 lights), the world is SAVED
+as a scene file and LOADED back (rt_world_save_scene / rt_world_load_scene), and the loaded scene is
+  * checked against the CPU oracle on a small frame (radiance as u32, cast counts) with every variant asked for,
+  * timed on a frame whose size keeps a run in seconds (1920x1080 up to a few thousand triangles, smaller beyond).
+One JSON line per (level, variant): triangles, frame, ms per frame, Mrays/s, G triangle-tests/s (casts x T / time: what a
+brute-force cast costs algorithmically, main.rs:183-262), and the scene's size in HBM.
+"""
+import argparse
+import json
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--levels", type=int, nargs="+", default=[0, 1, 2, 3, 4, 5, 6])
+ap.add_argument("--variants", type=int, nargs="+", default=[18, 2, 3])
+ap.add_argument("--spherize", action="store_true")
+ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen per size)")
+ap.add_argument("--no-parity", action="store_true")
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+
+import numpy as np
+import torch
+
+import homework_18_graphics_raytracer_amd as rt
+from homework_18_graphics_raytracer_amd import _capi
+
+lib = _capi.amd_lib()
+cam = rt.reference_camera()
+lines = []
+with tempfile.TemporaryDirectory() as tmp:
+    for level in a.levels:
+        obj = Path(tmp) / f"dodecahedron_l{level}.obj"
+        cmd = [sys.executable, str(ROOT / "tools" / "make_tessellated_obj.py"), rt.DEFAULT_OBJ, str(obj), "--levels", str(level)]
+        subprocess.run(cmd + (["--spherize"] if a.spherize else []), check=True, capture_output=True)
+        built = rt.reference_world(str(obj))
+        path = Path(tmp) / f"scene_l{level}.rtscene"
+        built.save_scene(path, cam)
+        world, file_cam = rt.World.load_scene(path)
+        desc = world.desc()
+        T = desc.n_triangles
+        scene = rt.Scene(world)
+        parity = None
+        if not a.no_parity:
+            import _oracle
+
+            small = rt.Frame.full(64, 48, 5) if T > 40000 else rt.Frame.full(128, 96, 5)
+            want, wcasts = _oracle.render_whitted(desc, file_cam, small)
+            parity = True
+            for v in a.variants:
+                _capi.check(lib.rt_set_variant(v))
+                got, casts = rt.render_whitted_numpy(scene, file_cam, small)
+                same = ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all() and casts == wcasts
+                parity = parity and bool(same)
+                if not same:
+                    print(f"PARITY MISS level {level} variant {v}", file=sys.stderr)
+        # frame size by scene size: a brute-force cast is linear in T
+        if T <= 3000:
+            W, H = 1920, 1080
+        elif T <= 40000:
+            W, H = 960, 540
+        else:
+            W, H = 480, 270
+        frame = rt.Frame.full(W, H, a.depth)
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for v in a.variants:
+            _capi.check(lib.rt_set_variant(v))
+            rt.render_whitted(scene, file_cam, frame, out=out, ray_count=cnt)  # warm-up
+            torch.cuda.synchronize()
+            cnt.zero_()
+            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            rt.render_whitted(scene, file_cam, frame, out=out, ray_count=cnt)
+            torch.cuda.synchronize()
+            first = time.perf_counter() - t0
+            n = a.frames or max(1, min(20, int(1.0 / max(first, 1e-4))))
+            cnt.zero_()
+            e0.record()
+            for _ in range(n):
+                rt.render_whitted(scene, file_cam, frame, out=out, ray_count=cnt)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            casts = int(cnt.item()) // n
+            rec = {"level": level, "spherize": a.spherize, "triangles": T, "spheres": desc.n_spheres, "variant": v,
+                   "lds_staged": bool(v & 1) and not (v & 16) and T * 128 <= 96 * 1024,
+                   "scene_bytes_device": T * (128 + 64), "scene_file_bytes": path.stat().st_size,
+                   "width": W, "height": H, "depth": a.depth, "frames": n, "ms_per_frame": round(ms, 4), "casts_per_frame": casts,
+                   "Mrays_per_s": round(casts / ms / 1e3, 2), "Gtri_tests_per_s": round(casts * T / ms / 1e6, 2),
+                   "parity_vs_oracle_small_frame": parity}
+            lines.append(rec)
+            print(json.dumps(rec), flush=True)
+        _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
+        del scene
+if a.out:
+    with open(a.out, "w") as f:
+        for rec in lines:
+            f.write(json.dumps(rec) + "\n")
