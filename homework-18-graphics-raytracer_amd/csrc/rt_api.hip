@@ -215,6 +215,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null array with non-zero count");
     if ((uint64_t)desc->n_triangles + desc->n_spheres >= 0x1fffffffull)
         return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: too many primitives");
+    if (desc->n_triangles > RT_MAX_TRIANGLES)
+        return fail(RT_ERR_UNSUPPORTED, "rt_scene_create: more than 2^24 triangles (the path is brute force by definition: one cast tests them all)");
     for (uint32_t i = 0; i < desc->n_triangles; ++i)
         if (desc->triangles[i].object_index >= desc->n_materials)
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: triangle object_index out of range");
@@ -390,6 +392,24 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
             }
             i = j;
         }
+    }
+    /* triangles on their predecessor's plane (rt_device_scene.h RT_TRI_FOLLOWS): same segment; n and d equal bit for bit, or
+     * (WEAK) equal up to the signs of zero components */
+    if (getenv("RT_AMD_NO_PLANE_SHARING") == nullptr && desc->n_materials <= RT_TRI_OBJ_MASK) { /* A/B switch; results are the same either way */
+        const bool weak_ok = getenv("RT_AMD_NO_WEAK_PLANE_SHARING") == nullptr;
+        for (const rt::DevSegment &g : segments)
+            for (uint32_t i = g.first + 1u; i < g.first + g.count; ++i) {
+                const float a[4] = {tris[i - 1u].n[0], tris[i - 1u].n[1], tris[i - 1u].n[2], tris[i - 1u].d};
+                const float b[4] = {tris[i].n[0], tris[i].n[1], tris[i].n[2], tris[i].d};
+                bool exact = true, weak = true;
+                for (int k = 0; k < 4; ++k) {
+                    const bool same_bits = memcmp(&a[k], &b[k], sizeof(float)) == 0;
+                    exact = exact && same_bits;
+                    weak = weak && (same_bits || (a[k] == 0.0f && b[k] == 0.0f));
+                }
+                if (exact) tris[i].obj |= RT_TRI_FOLLOWS;
+                else if (weak && weak_ok) tris[i].obj |= RT_TRI_FOLLOWS | RT_TRI_FOLLOWS_WEAK;
+            }
     }
     std::vector<rt::DevSphere> spheres(desc->n_spheres);
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {

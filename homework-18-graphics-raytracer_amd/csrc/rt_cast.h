@@ -120,11 +120,13 @@ __device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *
 #ifdef RT_DIAG_STAGES /* diagnostic build: python tools/gen_cast_asm.py --count-stages > csrc/rt_cast_asm_diag.h */
 #include "rt_cast_asm_diag.h"
 #define RT_STAGE_OPERANDS , "+v"(stage_counts[0]), "+v"(stage_counts[1]), "+v"(stage_counts[2]), "+v"(stage_counts[3]), "+v"(stage_counts[4]), "+v"(stage_counts[5]), "+v"(stage_counts[6]), "+v"(stage_counts[7])
-static __device__ unsigned long long g_stage_totals[8]; /* per translation unit; read with RT_DIAG_STAGE_READER(name) */
+/* [0] planes evaluated (cull), [1] divides, [2] plane points, [3..5] signed areas, [6] accepts, [7] triangles that got past
+ * "exclusion + nearest" (leaders and followers), [8] calls of the loop (per wave) */
+static __device__ unsigned long long g_stage_totals[9]; /* per translation unit; read with RT_DIAG_STAGE_READER(name) */
 #define RT_DIAG_STAGE_READER(name)                                                                              \
-    extern "C" int name(unsigned long long *out8, int reset) {                                                  \
-        if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_stage_totals), 8 * sizeof(unsigned long long)) != hipSuccess) return -1; \
-        if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_stage_totals), z, sizeof z) != hipSuccess) return -1; } \
+    extern "C" int name(unsigned long long *out9, int reset) {                                                  \
+        if (hipMemcpyFromSymbol(out9, HIP_SYMBOL(rt::g_stage_totals), 9 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[9] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_stage_totals), z, sizeof z) != hipSuccess) return -1; } \
         return 0;                                                                                               \
     }
 #else
@@ -158,9 +160,11 @@ struct TriBest {
 };
 
 /* The asm part over the triangle range [index_base, index_base + n): continues `best` under the reference's sequential
- * rule (ranges must be visited in index order). */
+ * rule (ranges must be visited in index order).  The loop addresses the records of a call with a 32-bit byte offset, so
+ * n * 128 must stay below 2^32: rt_scene_create refuses scenes of more than RT_MAX_TRIANGLES triangles.  The first triangle
+ * of a call is treated as the leader of its plane whatever its record says, so a range may start anywhere. */
 __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uint32_t n, uint32_t index_base, const Ray &ray,
-                                                   const CastMasks &m, TriBest *best) {
+                                                        const CastMasks &m, TriBest *best) {
     const bool ex_some = (ray.excl >> 31) != 0u;
     const uint32_t ex_prim = ray.excl & 0x1fffffffu;
     const uint32_t exid = (ex_some && ex_prim >= index_base && ex_prim - index_base < n) ? ex_prim - index_base : 0xffffffffu;
@@ -185,8 +189,8 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
                  : RT_CAST_ASM_CLOBBERS);
 #ifdef RT_DIAG_STAGES
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { /* first active lane: the counts are wave-uniform */
-        for (int k = 0; k < 7; ++k) atomicAdd(&g_stage_totals[k], (unsigned long long)stage_counts[k]);
-        atomicAdd(&g_stage_totals[7], 1ull); /* asm calls (per wave) */
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_stage_totals[k], (unsigned long long)stage_counts[k]);
+        atomicAdd(&g_stage_totals[8], 1ull); /* asm calls (per wave) */
     }
 #endif
     best->t = best_t;
@@ -312,7 +316,7 @@ __device__ __forceinline__ HitGeom finish_hit(const KernelScene &sc, const Ray &
     if ((uint32_t)r.prim < sc.n_triangles) {
         const DevTri &T = sc.tris[r.prim];
         const DevTriAttr &A = sc.attrs[r.prim];
-        h.obj = T.obj;
+        h.obj = T.obj & RT_TRI_OBJ_MASK; /* bit 31 is the loop's "same plane as the previous triangle" flag */
         const V3 bary = v3(r.a0, r.a1, r.a2) / T.area;
         /* Matrix3::from_cols(n0,n1,n2) * bary: rows dotted with bary */
         const V3 tmp = v3(dot(v3(A.n0[0], A.n1[0], A.n2[0]), bary),

@@ -32,9 +32,21 @@
 
 namespace rt {
 
+/* DevTri::obj: the object (material) index, and in bit 31 FOLLOWS — the triangle's plane (n and d) is the previous
+ * triangle's and both belong to the same segment, e.g. the second half of a square() (main.rs:741-746): the intersection
+ * loop then reuses n.d, t, the plane point and the culling / t > 0 mask of the previous triangle instead of recomputing
+ * identical values (rt_cast_asm.h).  Bit 30 (WEAK, with bit 31): the two planes are equal only up to the signs of zero
+ * components — (-0, 1, 0) after (0, 1, 0), what triangle() (main.rs:730-739) gives the two halves of most axis-aligned
+ * squares — and the loop shares the plane only while no lane has n.d == 0, the one case in which a zero's sign reaches a
+ * result (rt_cast_asm.h / tools/gen_cast_asm.py).  Purely a saving: the values are the same either way. */
+#define RT_MAX_TRIANGLES (1u << 24) /* 2 GiB of DevTri records; the loop's byte offset is 32 bits wide */
+#define RT_TRI_FOLLOWS 0x80000000u
+#define RT_TRI_FOLLOWS_WEAK 0x40000000u
+#define RT_TRI_OBJ_MASK 0x3fffffffu
+
 struct alignas(32) DevTri {
     float n[3];  float d;          /* plane */
-    float v0[3]; uint32_t obj;
+    float v0[3]; uint32_t obj;     /* object index | RT_TRI_FOLLOWS */
     float v1[3]; float area;       /* area of the whole triangle (barycentric denominator) */
     float v2[3]; float bq;         /* bounding sphere: 1.05 R^2, +inf = filter off (see below) */
     float e0[3]; float bcx;        /* v2 - v1            | bounding-sphere centre x */

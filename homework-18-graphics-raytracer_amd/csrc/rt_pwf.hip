@@ -89,6 +89,12 @@ namespace rt {
 #ifndef PA_SLEEP
 #define PA_SLEEP 16
 #endif
+#ifndef PA_SHADE_DL
+#define PA_SHADE_DL 0 /* 1: a SHADE item carries the light as its producer evaluated it (96 B instead of 80 B) so that the consumer
+                       * need not evaluate it again (for a spot light an acos and a powf in binary64).  Measured SLOWER, 1.51 ms per
+                       * frame against 1.28 ms (profiles/README.md, round 2): the sixth field costs more than the arithmetic saves */
+#endif
+#define PA_SHADE_U4 (PA_SHADE_DL ? 6u : 5u) /* uint4s per SHADE item */
 #define PA_SEALED 0x80000000u
 #define PA_SPIN_LIMIT (1u << 22)
 
@@ -109,6 +115,21 @@ struct PaShared {
     uint32_t done;            /* all waves idle at once: the queues are final */
     uint32_t abort;
 };
+
+#ifdef PA_STATS
+/* diagnostic build: wave time by phase (s_memtime ticks, summed over all waves) and chunk / lane counts by item type:
+ * [0..3] find work, [4..7] load items, [8..11] the cast, [12..15] after the cast — each by type NODE(0) REFR(1) TILE(2)
+ * SHADE(3); [16..19] chunks, [20..23] active lanes; [24] sleep/idle time, [25] fold */
+__device__ unsigned long long pa_phase_stats[32];
+#define PA_TICK() __builtin_readcyclecounter()
+#endif
+
+/* Items and records are stored field-major within pages of 64: field f of entry e sits at ((e >> 6) * F + f) * 64 + (e & 63)
+ * (in uint4s).  The 64 lanes of a chunk hold 64 consecutive entries, so every load and store of a field is one contiguous
+ * kilobyte (16 cache lines) instead of 64 pieces a record apart (64 lines): the queues' traffic is the same, the number of
+ * lines the vector-memory pipeline touches a quarter.  pa_entry() returns the address of field 0; field f is 64 * f further. */
+#define PA_F(f) ((f) * 64u)
+__device__ __forceinline__ size_t pa_entry(uint32_t e, uint32_t fields) { return ((size_t)(e >> 6) * fields << 6) + (e & 63u); }
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -172,8 +193,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     unsigned char *arena = pp.arena + (size_t)blockIdx.x * pp.arena_stride;
     uint4 *node_in = reinterpret_cast<uint4 *>(arena);                 /* node_cap x 2: ray, exclusion|mode|depth, contribution */
     uint4 *nodes = node_in + (size_t)pp.node_cap * 2u;                   /* node_cap x 2: shade term, rc | fc, decay, children   */
-    uint4 *shade_q = nodes + (size_t)pp.node_cap * 2u;                   /* ring_cap x 5 */
-    uint4 *refr_q = shade_q + (size_t)pp.ring_cap * 5u;                  /* ring_cap x 3 */
+    uint4 *shade_q = nodes + (size_t)pp.node_cap * 2u;                   /* ring_cap x PA_SHADE_U4 */
+    uint4 *refr_q = shade_q + (size_t)pp.ring_cap * PA_SHADE_U4;         /* ring_cap x 3 */
     uint32_t *tile_list = reinterpret_cast<uint32_t *>(refr_q + (size_t)pp.ring_cap * 3u); /* (tile, first root node) pairs */
     const uint32_t ring_mask = pp.ring_cap - 1u;
     const uint32_t tile_cap = pp.node_cap / 64u;
@@ -202,12 +223,17 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
 #ifdef PA_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t st_hist[5] = {0u, 0u, 0u, 0u, 0u}; /* chunks by item count: <= 8, <= 16, <= 32, < 64, 64 */
+    unsigned long long ph[26];
+    for (int k = 0; k < 26; ++k) ph[k] = 0ull;
 #endif
 
     for (;;) {
         if (lds_load(&S.done) != 0u || lds_load(&S.abort) != 0u) break;
 
         /* ---- find work (lane 0 decides, the wave follows) ---- */
+#ifdef PA_STATS
+        const unsigned long long ph_t0 = PA_TICK();
+#endif
         uint32_t type = PA_T_NONE, start = 0u, count = 0u;
         if (lane == 0u) {
             const uint32_t gen = lds_load(&S.gen); /* before looking: a publish during the look must not be slept through */
@@ -292,6 +318,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         type = (uint32_t)__builtin_amdgcn_readfirstlane((int)type);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
+#ifdef PA_STATS
+        const unsigned long long ph_t1 = PA_TICK();
+        if (type == PA_T_NONE) ph[24] += ph_t1 - ph_t0;
+        const uint32_t ph_k = type == PA_T_NODE ? 0u : (type == PA_T_REFR ? 1u : (type == PA_T_TILE ? 2u : 3u));
+#endif
         if (type == PA_T_NONE) continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the page's items were written before they were counted */
         /* the dependent chains issue ahead of fresh tiles, and those ahead of the filler (1.41 -> 1.38 ms) */
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
              * n.alloc, so they must not look like nodes (level 0 is never folded) */
             if (!active && id < pp.node_cap) fold_level[id] = 0u;
             if (active) {
-                const uint4 a = node_in[(size_t)id * 2u], b = node_in[(size_t)id * 2u + 1u];
+                const uint4 a = node_in[pa_entry(id, 2u)], b = node_in[pa_entry(id, 2u) + PA_F(1u)];
                 req.o = v3(puf(a.x), puf(a.y), puf(a.z));
                 req.d = v3(puf(a.w), puf(b.x), puf(b.y));
                 req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
@@ -371,8 +402,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
         } else if (type == PA_T_REFR) {
             if (active) {
-                const uint4 *t = refr_q + (size_t)((start + lane) & ring_mask) * 3u;
-                const uint4 a = t[0], b = t[1], c = t[2];
+                const uint4 *t = refr_q + pa_entry((start + lane) & ring_mask, 3u);
+                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)];
                 req.o = v3(puf(a.x), puf(a.y), puf(a.z));
                 req.d = v3(puf(a.w), puf(b.x), puf(b.y));
                 req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
@@ -386,14 +417,23 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
         } else { /* PA_T_SHADE */
             if (active) {
-                const uint4 *t = shade_q + (size_t)((start + lane) & ring_mask) * 5u;
-                const uint4 a = t[0], b = t[1], c = t[2], d = t[3], e = t[4];
+                const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
+#if PA_SHADE_DL
+                /* before the cast only what the shadow ray needs: the shaded point, the primitive to exclude and the light's
+                 * direction as the producer evaluated it (approximate_into_directional of light_i at spos) */
+                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)];
+                id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
+                spos = v3(puf(b.x), puf(b.y), puf(b.z));
+                dl.direction = v3(puf(a.w), puf(b.w), puf(reinterpret_cast<const uint32_t *>(t + PA_F(2u))[3]));
+#else
+                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
                 id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
                 spos = v3(puf(b.x), puf(b.y), puf(b.z)); sum.x = puf(b.w);
                 adj_n = v3(puf(c.x), puf(c.y), puf(c.z)); sum.y = puf(c.w);
                 in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
                 sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z));
                 do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl); /* always true for a queued item */
+#endif
                 req.o = spos;
                 req.d = -dl.direction;
                 req.mode = FACE_BACK;
@@ -402,6 +442,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         }
 
         /* ---- the cast: the one place the intersection loop is instantiated ---- */
+#ifdef PA_STATS
+        const unsigned long long ph_t2 = PA_TICK();
+#endif
         CastResult cr;
         cr.prim = -1;
         cr.t = 0.0f;
@@ -411,6 +454,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             cr = cast_asm(sc, req);
             casts += 1u;
         }
+#ifdef PA_STATS
+        const unsigned long long ph_t3 = PA_TICK();
+#endif
 
         if (type == PA_T_NODE) {
             /* ---- ray_trace after its cast (main.rs:475-505) ---- */
@@ -443,55 +489,67 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     }
                 }
                 /* depth == 0 (main.rs:488-490): the value is the unscaled shade */
-                if (want_shade) {
-                    const Mat m = material_approx(rm, nh.u, nh.v);
-                    adj_n = adjust_normal(m.normal, nh.normal); /* main.rs:410 */
-                    sdiffuse = m.diffuse;
-                    light_i = 0u;
-                    want_shade = next_shadow_ray(sc, &light_i, nh.pos, adj_n, &dl); /* no light needs a cast: get_shade = black */
-                }
             }
-            /* the record first: REFR items refer to it, and its children are written into it below */
+            /* The chain first: the record (REFR items refer to it, and its children are written into it below), the reflection
+             * child and the ray into the glass are written and published BEFORE get_shade's preparation below (a normal-map
+             * sincos, cgmath's from_arc, a spot light's acos and powf in binary64: about half of this block) — every
+             * microsecond here is on the frame's critical path, the SHADE item is not. */
             const uint32_t k_refl = lds_append(&S.n.alloc, want_refl);
             const bool overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
             if (want_refl && !overflow) rec_cr = k_refl;
             if (active) {
-                nodes[(size_t)id * 2u] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
-                nodes[(size_t)id * 2u + 1u] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
+                nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
+                nodes[pa_entry(id, 2u) + PA_F(1u)] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
                 if (!from_tile) fold_level[id] = (unsigned char)((cr.prim >= 0 && depth > 0u) ? depth : 0u); /* roots are folded by tile */
             }
             /* reflection child (get_reflect, main.rs:328-341) */
             if (want_refl && !overflow) {
                 const V3 d = reflect_dir(nh.normal, req.d);
                 const uint32_t word = pack_excl(nh.prim, nh.bf ? FACE_FRONT : FACE_BACK) | (req.mode << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
-                node_in[(size_t)k_refl * 2u] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(d.x));
-                node_in[(size_t)k_refl * 2u + 1u] = make_uint4(pfu(d.y), pfu(d.z), word, pfu(contribution * rc));
-            }
-            /* the first shadow cast of get_shade */
-            const uint32_t k_shade = lds_append(&S.s.alloc, want_shade);
-            if (want_shade) {
-                uint4 *t = shade_q + (size_t)(k_shade & ring_mask) * 5u;
-                t[0] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), 0u);
-                t[1] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(0.0f));
-                t[2] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(0.0f));
-                t[3] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
-                t[4] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+                node_in[pa_entry(k_refl, 2u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(d.x));
+                node_in[pa_entry(k_refl, 2u) + PA_F(1u)] = make_uint4(pfu(d.y), pfu(d.z), word, pfu(contribution * rc));
             }
             /* the ray into the glass (main.rs:358-366) */
             const uint32_t k_refr = lds_append(&S.f.alloc, want_refr);
             if (want_refr) {
-                uint4 *t = refr_q + (size_t)(k_refr & ring_mask) * 3u;
+                uint4 *t = refr_q + pa_entry(k_refr & ring_mask, 3u);
                 const uint32_t word = pack_excl(nh.prim, FACE_FRONT) | (FACE_BACK << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
-                t[0] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(inside_d.x));
-                t[1] = make_uint4(pfu(inside_d.y), pfu(inside_d.z), word, id);
-                t[2] = make_uint4(nh.obj, pfu(contribution * fc), pfu(0.0f), 0xffffffffu);
+                t[PA_F(0u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(inside_d.x));
+                t[PA_F(1u)] = make_uint4(pfu(inside_d.y), pfu(inside_d.z), word, id);
+                t[PA_F(2u)] = make_uint4(nh.obj, pfu(contribution * fc), pfu(0.0f), 0xffffffffu);
             }
-            /* everything is written: count it in */
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull; /* then the frame is abandoned: nothing to count in */
             pa_publish(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
-            pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
             pa_publish(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
+            /* get_shade up to its first shadow cast (main.rs:407-433) */
+            if (want_shade) {
+                const rt_material &rm = sc.materials[nh.obj];
+                const Mat m = material_approx(rm, nh.u, nh.v);
+                adj_n = adjust_normal(m.normal, nh.normal); /* main.rs:410 */
+                sdiffuse = m.diffuse;
+                light_i = 0u;
+                want_shade = next_shadow_ray(sc, &light_i, nh.pos, adj_n, &dl); /* no light needs a cast: get_shade = black */
+            }
+            const uint32_t k_shade = lds_append(&S.s.alloc, want_shade);
+            if (want_shade) {
+                uint4 *t = shade_q + pa_entry(k_shade & ring_mask, PA_SHADE_U4);
+#if PA_SHADE_DL
+                t[PA_F(0u)] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), pfu(dl.direction.x));
+                t[PA_F(1u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(dl.direction.y));
+                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(dl.direction.z));
+                t[PA_F(3u)] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
+                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), pfu(0.0f));
+                t[PA_F(5u)] = make_uint4(pfu(dl.color.x), pfu(dl.color.y), pfu(dl.color.z), pfu(0.0f));
+#else
+                t[PA_F(0u)] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), 0u);
+                t[PA_F(1u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(0.0f));
+                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(0.0f));
+                t[PA_F(3u)] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
+                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+#endif
+            }
+            pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
         } else if (type == PA_T_REFR) {
             /* ---- one step of get_refract (main.rs:371-403) ---- */
             bool requeue = false, escape = false;
@@ -522,34 +580,49 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     esc_o = ih.pos;
                     esc_d = normalize(out_dir);
                     esc_excl = pack_excl(ih.prim, FACE_BACK);
-                    decay = rtdm::powf(rm.opaque_decay, travel); /* main.rs:508 */
                 }
             }
             const uint32_t k_again = lds_append(&S.f.alloc, requeue);
             if (requeue) {
-                uint4 *t = refr_q + (size_t)(k_again & ring_mask) * 3u;
+                uint4 *t = refr_q + pa_entry(k_again & ring_mask, 3u);
                 const uint32_t word = req.excl | (req.mode << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
-                t[0] = make_uint4(pfu(req.o.x), pfu(req.o.y), pfu(req.o.z), pfu(req.d.x));
-                t[1] = make_uint4(pfu(req.d.y), pfu(req.d.z), word, id);
-                t[2] = make_uint4(obj, pfu(contribution), pfu(travel), (uint32_t)retry);
+                t[PA_F(0u)] = make_uint4(pfu(req.o.x), pfu(req.o.y), pfu(req.o.z), pfu(req.d.x));
+                t[PA_F(1u)] = make_uint4(pfu(req.d.y), pfu(req.d.z), word, id);
+                t[PA_F(2u)] = make_uint4(obj, pfu(contribution), pfu(travel), (uint32_t)retry);
             }
             const uint32_t k_child = lds_append(&S.n.alloc, escape);
             const bool overflow = escape && k_child + lds_load(&S.root_alloc) >= pp.node_cap;
             if (escape && !overflow) {
                 const uint32_t word = esc_excl | (FACE_FRONT << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
-                node_in[(size_t)k_child * 2u] = make_uint4(pfu(esc_o.x), pfu(esc_o.y), pfu(esc_o.z), pfu(esc_d.x));
-                node_in[(size_t)k_child * 2u + 1u] = make_uint4(pfu(esc_d.y), pfu(esc_d.z), word, pfu(contribution));
-                uint32_t *rec = reinterpret_cast<uint32_t *>(nodes + (size_t)id * 2u);
-                rec[5] = pfu(decay);
-                rec[7] = k_child;
+                node_in[pa_entry(k_child, 2u)] = make_uint4(pfu(esc_o.x), pfu(esc_o.y), pfu(esc_o.z), pfu(esc_d.x));
+                node_in[pa_entry(k_child, 2u) + PA_F(1u)] = make_uint4(pfu(esc_d.y), pfu(esc_d.z), word, pfu(contribution));
+                reinterpret_cast<uint32_t *>(nodes + pa_entry(id, 2u) + PA_F(1u))[3] = k_child; /* record word 7: the refraction child */
             }
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull;
             pa_publish(ready_f, ring_page_mask, requeue, k_again, &S.gen);
             pa_publish(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
+            /* the decay (a powf in binary64) is only read by the fold: after the child is on its way */
+            if (escape && !overflow) {
+                decay = rtdm::powf(sc.materials[obj].opaque_decay, travel); /* main.rs:508 */
+                reinterpret_cast<uint32_t *>(nodes + pa_entry(id, 2u) + PA_F(1u))[1] = pfu(decay); /* record word 5 */
+            }
         } else {
             /* ---- one light of get_shade (main.rs:435-461) ---- */
             bool again = false;
+#if PA_SHADE_DL
+#ifdef PA_SHADE_BARRIER
+            asm volatile("" ::: "memory"); /* the rest of the item is read here, not before the cast */
+#endif
+            if (active) {
+                const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
+                const uint4 c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)], f = t[PA_F(5u)];
+                adj_n = v3(puf(c.x), puf(c.y), puf(c.z));
+                in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.x = puf(d.w);
+                sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z)); sum.y = puf(e.w);
+                dl.color = v3(puf(f.x), puf(f.y), puf(f.z)); sum.z = puf(f.w);
+            }
+#endif
             if (active) {
                 const rt_material &rm = sc.materials[obj];
                 if (do_cast) {
@@ -591,7 +664,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
                         acc = sum * shade_contribution;
                     }
-                    float *rec = reinterpret_cast<float *>(nodes + (size_t)id * 2u);
+                    float *rec = reinterpret_cast<float *>(nodes + pa_entry(id, 2u));
                     rec[0] = acc.x;
                     rec[1] = acc.y;
                     rec[2] = acc.z;
@@ -599,15 +672,35 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
             const uint32_t k_again = lds_append(&S.s.alloc, again);
             if (again) {
-                uint4 *t = shade_q + (size_t)(k_again & ring_mask) * 5u;
-                t[0] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), 0u);
-                t[1] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
-                t[2] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
-                t[3] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
-                t[4] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+                uint4 *t = shade_q + pa_entry(k_again & ring_mask, PA_SHADE_U4);
+#if PA_SHADE_DL
+                t[PA_F(0u)] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), pfu(dl.direction.x));
+                t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(dl.direction.y));
+                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(dl.direction.z));
+                t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.x));
+                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), pfu(sum.y));
+                t[PA_F(5u)] = make_uint4(pfu(dl.color.x), pfu(dl.color.y), pfu(dl.color.z), pfu(sum.z));
+#else
+                t[PA_F(0u)] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), 0u);
+                t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
+                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
+                t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
+                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+#endif
             }
             pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
         }
+#ifdef PA_STATS
+        {
+            const unsigned long long ph_t4 = PA_TICK();
+            ph[0 + ph_k] += ph_t1 - ph_t0;
+            ph[4 + ph_k] += ph_t2 - ph_t1;
+            ph[8 + ph_k] += ph_t3 - ph_t2;
+            ph[12 + ph_k] += ph_t4 - ph_t3;
+            ph[16 + ph_k] += 1ull;
+            ph[20 + ph_k] += count;
+        }
+#endif
     }
 
 #ifdef PA_STATS /* diagnostic build: per-workgroup main-loop and fold times (100 MHz ticks) into the global words */
@@ -637,19 +730,19 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 for (uint32_t k = 0; k < 16u; ++k) {
                     if (lv[k] != left) continue;
                     const uint32_t id = first + k * PA_THREADS;
-                    const uint4 a = nodes[(size_t)id * 2u], b = nodes[(size_t)id * 2u + 1u];
+                    const uint4 a = nodes[pa_entry(id, 2u)], b = nodes[pa_entry(id, 2u) + PA_F(1u)];
                     const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
                     V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
                     if (b.z != PW_NO_CHILD) {
-                        const uint4 c = nodes[(size_t)b.z * 2u];
+                        const uint4 c = nodes[pa_entry(b.z, 2u)];
                         reflection = v3(puf(c.x), puf(c.y), puf(c.z));
                     }
                     if (b.w != PW_NO_CHILD) {
-                        const uint4 c = nodes[(size_t)b.w * 2u];
+                        const uint4 c = nodes[pa_entry(b.w, 2u)];
                         refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay; /* main.rs:508 */
                     }
                     const V3 value = (v3(puf(a.x), puf(a.y), puf(a.z)) + reflection * rc) + refraction * fc;
-                    float *rec = reinterpret_cast<float *>(nodes + (size_t)id * 2u);
+                    float *rec = reinterpret_cast<float *>(nodes + pa_entry(id, 2u));
                     rec[0] = value.x;
                     rec[1] = value.y;
                     rec[2] = value.z;
@@ -678,8 +771,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     slot[j] = first_slot + lane;
                 }
                 if (live[j]) {
-                    ra[j] = nodes[(size_t)id[j] * 2u];
-                    rb[j] = nodes[(size_t)id[j] * 2u + 1u];
+                    ra[j] = nodes[pa_entry(id[j], 2u)];
+                    rb[j] = nodes[pa_entry(id[j], 2u) + PA_F(1u)];
                 }
             }
             uint4 cr4[4], cf4[4];
@@ -687,8 +780,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             for (uint32_t j = 0; j < 4u; ++j) {
                 cr4[j] = cf4[j] = make_uint4(0u, 0u, 0u, 0u);
                 if (live[j] && rb[j].z != PW_FINAL) {
-                    if (rb[j].z != PW_NO_CHILD) cr4[j] = nodes[(size_t)rb[j].z * 2u];
-                    if (rb[j].w != PW_NO_CHILD) cf4[j] = nodes[(size_t)rb[j].w * 2u];
+                    if (rb[j].z != PW_NO_CHILD) cr4[j] = nodes[pa_entry(rb[j].z, 2u)];
+                    if (rb[j].w != PW_NO_CHILD) cf4[j] = nodes[pa_entry(rb[j].w, 2u)];
                 }
             }
 #pragma unroll
@@ -720,6 +813,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         const unsigned long long st_t3 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0u) { atomicAdd(pp.global + 8, (uint32_t)(st_t1 - st_t0)); atomicMax(pp.global + 9, (uint32_t)(st_t1 - st_t0)); } /* per wave: own loop */
         if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(pp.global + 20 + k, st_hist[k]);
+        if (lane == 0u) {
+            ph[25] = st_t3 - st_t2;
+            for (int k = 0; k < 26; ++k) atomicAdd(&pa_phase_stats[k], ph[k]);
+        }
         if (threadIdx.x == 0u) {
             atomicAdd(pp.global + 10, (uint32_t)(st_t2 - st_t0)); atomicMax(pp.global + 11, (uint32_t)(st_t2 - st_t0)); /* until the last wave left the loop */
             atomicAdd(pp.global + 12, (uint32_t)(st_t3 - st_t2)); atomicMax(pp.global + 13, (uint32_t)(st_t3 - st_t2)); /* fold */
@@ -752,7 +849,7 @@ __global__ void pwf_finish_kernel(uint32_t *global, uint32_t n_tiles, unsigned l
 
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap) {
     /* node inputs + records, the two rings, the tile list, one "folds at level" byte per node (barrier-free kernel) */
-    return ((size_t)node_cap * 4u + (size_t)ring_cap * 8u) * sizeof(uint4) + (size_t)(node_cap / 64u) * 2u * sizeof(uint32_t) +
+    return ((size_t)node_cap * 4u + (size_t)ring_cap * (3u + PA_SHADE_U4)) * sizeof(uint4) + (size_t)(node_cap / 64u) * 2u * sizeof(uint32_t) +
            (((size_t)node_cap + 15u) & ~(size_t)15u) + 256u;
 }
 
@@ -761,6 +858,15 @@ static uint32_t *g_pw_last_global = nullptr;
 extern "C" int rt_diag_read_pwf(uint32_t *out32) {
     if (!g_pw_last_global) return -1;
     return hipMemcpy(out32, g_pw_last_global, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+/* wave time by phase; reset != 0 clears the counters after reading */
+extern "C" int rt_diag_read_pwf_phases(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pa_phase_stats), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pa_phase_stats), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
 }
 #endif
 

@@ -110,6 +110,19 @@ RT_HD V3 get_diffuse(const Mat &m, V3 normal, V3 light_direction) {
     return cosine > 0.0f ? m.diffuse * cosine : v3(0.0f, 0.0f, 0.0f);
 }
 
+/* Is powf(x, y) certainly +0.0f?  For 0 <= x < 1 and finite y > 0: ln x <= x - 1, so y ln x <= y (x - 1); rtdm::powf returns
+ * 0.0f as soon as its binary64 product y * ln x is below -110 (rt_detmath.h; e^-110 is far below half the smallest binary32
+ * subnormal).  The test leaves a margin of 1 for the two binary32 roundings in y * (x - 1) (relative 2^-23) and the 2^-48
+ * of log_pos; x == 0 gives +0 by C99's pow(+0, y > 0).  Phong exponents here reach 1e5 (smoothness 1e-5, main.rs:866, 885,
+ * 935): outside the highlight the power underflows, and a wave none of whose lanes is inside one skips the binary64
+ * evaluation altogether.  Same bits as evaluating it (tests: GPU == oracle, which always evaluates). */
+RT_HD bool pow_underflows_to_zero(float x, float y) {
+#ifdef RT_NO_POW_SHORTCUT /* A/B */
+    return false;
+#endif
+    return x >= 0.0f && x < 1.0f && y > 0.0f && y <= 3.0e38f && (x == 0.0f || y * (x - 1.0f) < -111.0f);
+}
+
 /* materials.rs:55-66 */
 RT_HD V3 get_specular(const Mat &m, V3 normal, V3 view_direction, V3 light_direction) {
     const float cosine = dot(light_direction, normal);
@@ -119,7 +132,15 @@ RT_HD V3 get_specular(const Mat &m, V3 normal, V3 view_direction, V3 light_direc
     const float energy_conserving = (specular + 8.0f) / (8.0f * RT_F_PI);
     const float rv = dot(reflected, view_direction);
     const float clamped = (rv > 0.0f) ? rv : 0.0f; /* f32::max(0.0): NaN -> 0.0 */
-    const float amount = rtdm::powf(clamped, specular) * energy_conserving;
+    float power = 0.0f;
+    const bool zero = pow_underflows_to_zero(clamped, specular);
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* a wave none of whose lanes needs the binary64 evaluation branches around it (a select would evaluate it regardless) */
+    if (__builtin_amdgcn_ballot_w64(!zero) != 0ull) power = zero ? 0.0f : rtdm::powf(clamped, specular);
+#else
+    if (!zero) power = rtdm::powf(clamped, specular);
+#endif
+    const float amount = power * energy_conserving;
     return m.specular * amount;
 }
 

@@ -147,3 +147,37 @@ def axis_camera(eye, toward=(0.0, 0.0, -1.0)):
     cam.up = (0.0, 1.0, 0.0)
     cam.near = 0.0
     return cam
+
+
+def squares_world(seed, n_squares=10):
+    """Axis-aligned square()s with round coordinates, a few per object (so they stay plain runs, not clusters): each is two
+    triangles on one plane whose face normals differ at most in the signs of zero components — the pairs the intersection
+    loop shares a plane evaluation between (rt_device_scene.h RT_TRI_FOLLOWS / _WEAK) — plus a random triangle between
+    some of them, so that followers, non-followers and leaders alternate.  With axis_camera() from a grid point, rays
+    parallel to the planes (n.d == +-0: t = +-inf / NaN) and origins on them occur exactly."""
+    rng = np.random.default_rng(4000 + seed)
+    w = rt.World()
+    obj = None
+    for k in range(n_squares):
+        if k % 3 == 0:
+            obj = w.push_object(material(rng, "plain"))
+        axis = int(rng.integers(0, 3))
+        level = float(rng.integers(-2, 4)) * 0.5
+        lo = [float(rng.integers(-4, 2)) * 0.5 for _ in range(2)]
+        size = [float(rng.integers(1, 5)) * 0.5 for _ in range(2)]
+        u, v = [a for a in range(3) if a != axis]
+        corners = []
+        for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)) if rng.integers(0, 2) else ((0, 0), (0, 1), (1, 1), (1, 0)):
+            p = [0.0, 0.0, 0.0]
+            p[axis] = level
+            p[u] = lo[0] + du * size[0]
+            p[v] = lo[1] + dv * size[1]
+            corners.append(tuple(p))
+        obj.push_square(corners, [(0, 0), (0, 1), (1, 1), (1, 0)])
+        if rng.integers(0, 3) == 0:
+            c = rng.uniform(-1.5, 1.5, 3)
+            obj.push_flat_triangle((c + rng.normal(0, 0.5, (3, 3))).tolist(), rng.uniform(0, 1, (3, 2)).tolist())
+    w.push_object(material(rng, "plain")).push_sphere((0.3, 0.4, -0.2), 0.35)
+    for i in range(3):
+        w.push_light(light(rng, i % 3))
+    return w

@@ -59,6 +59,36 @@ def test_distributed_bit_exact(ctx, w, h, depth, epochs):
     assert np.array_equal(rng.download(), st)  # same number of draws everywhere: the streams stay in step
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_other_scenes_squares_clusters_and_random_triangles(seed):
+    """Scenes other than the reference's: axis-aligned squares (triangle pairs that share a plane evaluation in the
+    intersection loop), clustered boxes and random triangles with generative materials — incoherent scattered rays through
+    the same loop; blur 0 makes every primary ray of the axis-aligned camera exactly axis-parallel in some component."""
+    import _scenes
+
+    for world, cam, blur in ((_scenes.squares_world(seed), _scenes.axis_camera((0.5, 0.5, 3.0)), 0.0),
+                             (_scenes.squares_world(seed + 10), _scenes.camera(seed), 0.04),
+                             (_scenes.clustered_world(seed, n_boxes=3), _scenes.camera(seed), 0.02),
+                             (_scenes.random_world(seed, 40, 3), _scenes.camera(seed), 0.04)):
+        scene = rt.Scene(world)
+        frame = rt.Frame.full(64, 48, 5)
+        import torch
+
+        rng = rt.Rng(frame)
+        samples = torch.empty((3, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+        valid = torch.empty((3, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        rt.render_distributed(scene, cam, frame, rng, 3, focus=3.0, blur=blur, samples=samples, valid=valid, ray_count=cnt)
+        torch.cuda.synchronize()
+        st = _oracle.rng_init(frame)
+        ws, wv, wcasts = _oracle.render_distributed(world.desc(), cam, frame, st, 3, focus=3.0, blur=blur)
+        s = samples.cpu().numpy()
+        same = (s.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(s) & np.isnan(ws))
+        assert same.all(), f"{(~same).sum()} channels differ"
+        assert np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
+        assert np.array_equal(rng.download(), st)
+
+
 @pytest.mark.parametrize("cap_mb,epochs", [("1", 3), ("8", 3), ("8", 5)])
 def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs):
     """A small workspace cap makes the split pass run the call in batches (1 epoch; 2 + a short last one)."""

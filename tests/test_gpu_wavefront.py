@@ -153,6 +153,23 @@ def test_clustered_objects_degenerate_rays(seed, eye, variant):
         _check(world, _scenes.axis_camera(eye), rt.Frame.full(w, h, 5), budget=16, variant=variant)
 
 
+@pytest.mark.parametrize("variant", [PWF | 2, 2])
+@pytest.mark.parametrize("seed,eye,toward", [(1, (0.0, 0.5, 3.0), (0.0, 0.0, -1.0)), (2, (0.5, 1.0, 3.0), (0.0, 0.0, -1.0)),
+                                             (3, (3.0, 0.5, 0.0), (-1.0, 0.0, 0.0)), (4, (0.0, 3.0, 0.5), (0.0, -1.0, 0.0)),
+                                             (5, (-0.5, 0.0, 2.5), (0.0, 0.0, -1.0)), (6, (1.0, 1.5, 2.0), (0.0, 0.0, -1.0))])
+def test_plane_sharing_on_squares_with_degenerate_rays(seed, eye, toward, variant):
+    """square() pairs share one plane evaluation in the intersection loop (rt_device_scene.h RT_TRI_FOLLOWS / _WEAK).  Their
+    normals may differ in the signs of zero components, which reaches a result only through n.d == +-0 — exactly what an
+    axis-aligned camera on a grid point produces (rays parallel to planes, origins ON planes: t = +-inf, NaN, +-0)."""
+    world = _scenes.squares_world(seed)
+    cam = _scenes.axis_camera(eye, toward)
+    if toward[1] != 0.0:
+        cam.up = (0.0, 0.0, 1.0)
+    for w, h in ((64, 64), (65, 33)):
+        _check(world, cam, rt.Frame.full(w, h, 5), budget=16, variant=variant)
+    _check(world, _scenes.camera(seed), rt.Frame.full(96, 64, 6), budget=16, variant=variant)
+
+
 def test_two_streams_render_concurrently_with_their_own_workspaces(ref):
     """A scene may be rendered from several streams at once; each stream has its own arenas."""
     import torch

@@ -33,7 +33,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--world", type=int, default=1, help="render only rank 0's interleaved row band of this many ranks (a multi-GPU share)")
 args = ap.parse_args()
 
-ENV_KNOBS = ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC", "RT_AMD_NO_CLUSTERS", "RT_AMD_PWF_RING")
+ENV_KNOBS = ("RT_AMD_NO_SPHERE_FILTER", "RT_AMD_FILTER_MAX_FRAC", "RT_AMD_NO_CLUSTERS", "RT_AMD_PWF_RING", "RT_AMD_NO_PLANE_SHARING", "RT_AMD_NO_WEAK_PLANE_SHARING")
 world = rt.reference_world()
 cam = rt.reference_camera()
 desc = world.desc()

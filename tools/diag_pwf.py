@@ -34,3 +34,17 @@ print(f"until the WG's last wave left the loop: mean {g[10] / wgs / 100:.1f} us,
 print(f"fold: mean {g[12] / wgs / 100:.1f} us, max {g[13] / 100:.1f} us;  whole WG: min {g[16] / 100:.1f} us, max {g[17] / 100:.1f} us")
 h = [g[20 + k] for k in range(5)]
 print("chunks by item count (<=8, <=16, <=32, <64, 64):", h, "shares", [round(x / max(1, sum(h)), 3) for x in h])
+
+# wave time by phase (shader-clock ticks summed over all waves, both frames above; the shares are what matters)
+lib.rt_diag_read_pwf_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+ph = (C.c_ulonglong * 32)()
+assert lib.rt_diag_read_pwf_phases(ph, 1) == 0
+ph = list(ph)
+total = sum(ph[0:16]) + ph[24] + ph[25]
+names = ["NODE", "REFR", "TILE", "SHADE"]
+print(f"wave time by phase, share of {total:.3e} ticks (find / load / cast / after), chunks, mean lanes per chunk:")
+for k, n in enumerate(names):
+    chunks = max(1, ph[16 + k])
+    print(f"  {n:5s} find {ph[k] / total:6.3f}  load {ph[4 + k] / total:6.3f}  cast {ph[8 + k] / total:6.3f}  after {ph[12 + k] / total:6.3f}"
+          f"   chunks {ph[16 + k]:8d}  lanes/chunk {ph[20 + k] / chunks:5.1f}  ticks/chunk: load {ph[4 + k] / chunks:7.0f} cast {ph[8 + k] / chunks:7.0f} after {ph[12 + k] / chunks:7.0f}")
+print(f"  idle/sleep {ph[24] / total:6.3f}   fold {ph[25] / total:6.3f}")

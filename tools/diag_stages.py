@@ -20,16 +20,16 @@ world = rt.reference_world(); cam = rt.reference_camera(); desc = world.desc()
 frame = rt.Frame.full(W, H, depth)
 h = C.c_void_p(); assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0
 out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-names = ["cull", "divide", "p+sphere", "area0", "area1", "area2", "accept"]
+names = ["plane/cull", "divide", "point", "area0", "area1", "area2", "accept", "triangle"]
 lib.rt_diag_read_stages_pwf.argtypes = lib.rt_diag_read_stages_kernels.argtypes
 for variant, reader in ((2, lib.rt_diag_read_stages_kernels), (18, lib.rt_diag_read_stages_pwf)):
     lib.rt_set_variant(variant)
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 9)()
     reader(buf, 1)
     assert lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), None, None) == 0
     torch.cuda.synchronize()
     reader(buf, 1)
-    casts = buf[7]
+    casts = buf[8]
     print(f"variant {variant}: {casts} calls of the triangle loop (one per visited segment per call)")
     for k, n in enumerate(names):
         print(f"   {n:9s} {buf[k] / casts:7.2f} per call")

@@ -7,18 +7,23 @@ fixed by parity: IEEE binary32 mul/add/sub in the reference's order, the compile
 division sequence (v_div_scale / v_rcp / fma refinement / v_div_fmas / v_div_fixup), literal NaN behaviour of
 the comparisons.  What is hand-made is the control and data flow around it:
 
-  * one 112-byte scalar fetch per triangle (s_load_dwordx16 + x8 + x4) into a buffer of 28 SGPRs, issued one
-    triangle ahead; the other buffer is being tested meanwhile;
+  * one 112-byte scalar fetch per triangle (s_load_dwordx16 + x8 + x4, base + one offset register + immediates) into a
+    buffer of 28 SGPRs, issued one triangle ahead; the other buffer is being tested meanwhile;
   * lane predicates live in SGPR pairs and are combined with s_and/s_andn2/s_or; EXEC is never narrowed for the
-    arithmetic, so there is no save/restore nesting — three wave-level exits (after culling/exclusion, after
-    t <= 0, after inside+nearest) branch on SCC straight to the next triangle;
-  * the accept is the only EXEC switch: five instructions for the lanes that found a nearer hit.
+    arithmetic, so there is no save/restore nesting — wave-level exits (after culling, after t <= 0, after
+    exclusion + nearest, after the bounding-sphere test, after each signed area) branch on SCC straight to the next triangle;
+  * PLANE SHARING: a triangle flagged FOLLOWS (same n and d, bit for bit, as its predecessor: the second half of every
+    square(), main.rs:741-746) skips the plane part — n.d, the divide, the plane point and the culling / t > 0 mask are
+    those of the predecessor, still in registers; only exclusion, nearest, the bounding-sphere test and the signed areas
+    are the triangle's own.  The reference scene's 28 non-dodecahedron triangles are 14 such pairs;
+  * the accept is the only EXEC switch: six moves for the lanes that found a nearer hit.
 
 Hazards handled by construction (gfx9 family): >= 4 instructions between the VCC-writing v_div_scale and
 v_div_fmas; s_nop after v_rcp_f32 before its consumer (trans-use hazard on gfx940+); VALU-written masks are
 only consumed by SALU (interlocked) and branches use SCC, never VCCZ/EXECZ.
 
     python tools/gen_cast_asm.py > homework-18-graphics-raytracer_amd/csrc/rt_cast_asm.h
+    python tools/gen_cast_asm.py --count-stages > homework-18-graphics-raytracer_amd/csrc/rt_cast_asm_diag.h
 """
 
 # ---- operand map of the asm statement (see cast_asm() in rt_cast.h) ----
@@ -34,19 +39,13 @@ COUNT = "--count-stages" in sys.argv  # diagnostic build (RT_DIAG_STAGES): eight
 if COUNT:
     TEMPS.update({f"c{k}": 20 + k for k in range(8)})
     IN = {k: v + 8 for k, v in IN.items()}
-EARLY_AREA_EXITS = "--no-early-area-exits" not in sys.argv
-OUT_OF_LINE_EXCLUSION = "--inline-exclusion" not in sys.argv
 SPHERE_FILTER = "--no-sphere-filter" not in sys.argv  # conservative per-triangle bounding-sphere rejection of the plane hit point
-NEAREST_EARLY = "--nearest-late" not in sys.argv      # test !(best_t < t) right after t > 0 instead of after the areas
-ILP = "--ilp" in sys.argv  # interleave the three signed-area chains (and p) for a lone wave; one exit after all three
-XT = [f"v{k}" for k in range(148, 168)]  # extra temporaries of the ILP form: fixed VGPRs, named in the clobber list
 SLOW = {}
 
 # fixed scalar registers (all in the clobber list)
 # (s32/s33 are the ABI stack/frame pointers and s100/s101 are reserved by the compiler: stay inside s34..s99)
-S_PTR = "s[34:35]"
-S_PTR_LO, S_PTR_HI = "s34", "s35"
-S_I, S_N = "s36", "s37"
+S_OFF, S_I = "s34", "s35"  # byte offset of the record pair being fetched (the base stays in the input operand); loop index
+S_PLANE = "s[36:37]"       # lanes that passed culling and t > 0 on the current plane
 S_ALIVE, S_T1, S_T2 = "s[38:39]", "s[96:97]", "s[98:99]"
 S_EXSAVE = S_T2
 
@@ -73,10 +72,11 @@ def op(name):
 
 def loads(buf, offset):
     b = BUF[buf]
+    imm = lambda x: f" offset:{hex(x)}" if x else ""
     return [
-        f"s_load_dwordx16 {b['x16']}, {S_PTR}, {hex(offset)}",
-        f"s_load_dwordx8 {b['x8']}, {S_PTR}, {hex(offset + 0x40)}",
-        f"s_load_dwordx4 {b['x4']}, {S_PTR}, {hex(offset + 0x60)}",
+        f"s_load_dwordx16 {b['x16']}, {op('ptr')}, {S_OFF}{imm(offset)}",
+        f"s_load_dwordx8 {b['x8']}, {op('ptr')}, {S_OFF}{imm(offset + 0x40)}",
+        f"s_load_dwordx4 {b['x4']}, {op('ptr')}, {S_OFF}{imm(offset + 0x60)}",
     ]
 
 
@@ -105,32 +105,28 @@ def area(dst, e, vtx, p, w, c, tmp, n):
 
 
 def test(buf, label_next):
+    """One triangle.  A triangle whose record says FOLLOWS (bit 31 of its object word: rt_scene_create sets it when the
+    triangle's plane — n and d, bit for bit — is the previous triangle's, e.g. the second half of a square()) skips the
+    plane part: nd, t, p and the mask of lanes that passed culling and t > 0 (S_PLANE) are still in registers."""
     T = regs(buf)
     n = (T["nx"], T["ny"], T["nz"])
     d = (op("dx"), op("dy"), op("dz"))
     o = (op("ox"), op("oy"), op("oz"))
     r = [op(f"r{k}") for k in range(14)]
-    nd, num = r[13], r[12]  # num becomes t; nd stays live to the accept
+    nd, num = r[13], r[12]  # num becomes t; nd, t and p stay live for the triangles that follow on the same plane
     t = num
+    p = (r[0], r[1], r[2])
     L = []
     cnt = (lambda k: [f"v_add_u32 {op('c%d' % k)}, 1, {op('c%d' % k)}"]) if COUNT else (lambda k: [])
+    L += [f"s_bitcmp1_b32 {T['obj']}, 31", f"s_cbranch_scc1 .Lcast_follow{buf}_%=", f".Lcast_lead{buf}_%=:"]
+    # ---- the plane (main.rs:184-188, 202-205, 210): shared by every triangle that follows on it ----
     L += cnt(0)
     # nd = n . d ; bf = nd > 0
     L += dot_sv(nd, r[9], n, d)
     L += [f"v_cmp_lt_f32 vcc, 0, {nd}"]
-    # alive = bf ? keep_back : keep_front          (culling, main.rs:185-188)
-    L += [f"s_and_b64 {S_ALIVE}, vcc, {op('keep_back')}", f"s_andn2_b64 {S_T1}, {op('keep_front')}, vcc", f"s_or_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}"]
-    # exclusion: same primitive and (bf ? ex_if_back : ex_if_front)   (main.rs:190-200)
-    # Almost every triangle is excluded by no lane at all: test that first and keep the mask algebra out of line.
-    excl = [f"s_and_b64 {S_T1}, vcc, {op('ex_if_back')}", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
-            f"s_andn2_b64 {S_T1}, {op('ex_if_front')}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}"]
-    L += [f"v_cmp_eq_u32_e64 {S_T2}, {S_I}, {op('exid')}"]
-    if OUT_OF_LINE_EXCLUSION:
-        L += [f"s_cmp_lg_u64 {S_T2}, 0", f"s_cbranch_scc1 .Lcast_excl{buf}_%=", f".Lcast_excl{buf}_back_%=:"]
-        SLOW[buf] = [f".Lcast_excl{buf}_%=:"] + excl + [f"s_branch .Lcast_excl{buf}_back_%="]
-    else:
-        L += excl
-    L += [f"s_and_b64 {S_ALIVE}, {S_ALIVE}, exec", f"s_cbranch_scc0 {label_next}"]
+    # S_PLANE = bf ? keep_back : keep_front          (culling, main.rs:185-188)
+    L += [f"s_and_b64 {S_PLANE}, vcc, {op('keep_back')}", f"s_andn2_b64 {S_T1}, {op('keep_front')}, vcc", f"s_or_b64 {S_PLANE}, {S_PLANE}, {S_T1}",
+          f"s_and_b64 {S_PLANE}, {S_PLANE}, exec", f"s_cbranch_scc0 {label_next}"]
     # num = d - n . o                              (main.rs:203-204)
     L += cnt(1)
     L += dot_sv(r[9], r[10], n, o)
@@ -149,23 +145,44 @@ def test(buf, label_next):
           f"v_fma_f32 {q0}, -{q0}, {q}, {q1}",
           f"v_div_fmas_f32 {q0}, {q0}, {rc}, {q}",
           f"v_div_fixup_f32 {t}, {q0}, {nd}, {num}"]
-    # alive &= !(t <= 0)   (NaN passes, main.rs:205)
-    if NEAREST_EARLY:
-        # ... and alive &= !(best_t < t): a lane that already holds a nearer hit cannot accept this triangle whatever its
-        # areas are (main.rs:229-233 is one more `continue`; the order of the rejections is immaterial), best_t = NaN while None
-        L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc",
-              f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
-    else:
-        L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    # S_PLANE &= !(t <= 0)   (NaN passes, main.rs:205)
+    L += [f"v_cmp_nge_f32 vcc, 0, {t}", f"s_and_b64 {S_PLANE}, {S_PLANE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # p = o + d * t
     L += cnt(2)
-    p = (r[0], r[1], r[2])
-    if ILP:
-        L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}" for k in range(3)] + [f"v_add_f32 {p[k]}, {o[k]}, {p[k]}" for k in range(3)]
-    else:
-        for k in range(3):
-            L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
+    for k in range(3):
+        L += [f"v_mul_f32 {p[k]}, {d[k]}, {t}", f"v_add_f32 {p[k]}, {o[k]}, {p[k]}"]
+    # ---- this triangle (leaders fall in; followers enter here with the plane's registers) ----
+    L += [f".Lcast_tri{buf}_%=:"]
+    # exclusion (main.rs:190-200): same primitive and (bf ? ex_if_back : ex_if_front).  Almost every triangle is excluded
+    # by no lane at all: test that first and keep the mask algebra out of line.
+    # nearest (main.rs:229-233): a lane that already holds a nearer hit cannot accept this triangle whatever its areas are
+    # (one more `continue`; the order of the rejections is immaterial); best_t = NaN while None, equal t passes (the later
+    # primitive wins a tie)
+    L += [f"v_cmp_eq_u32_e64 {S_T2}, {S_I}, {op('exid')}",
+          f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}",
+          f"s_cmp_lg_u64 {S_T2}, 0", f"s_cbranch_scc1 .Lcast_excl{buf}_%=",
+          f"s_and_b64 {S_ALIVE}, {S_PLANE}, vcc",
+          f".Lcast_excl{buf}_back_%=:",
+          f"s_cbranch_scc0 {label_next}"]
+    SLOW[buf] = [f".Lcast_excl{buf}_%=:",
+                 f"s_and_b64 {S_ALIVE}, {S_PLANE}, vcc",
+                 f"v_cmp_lt_f32 vcc, 0, {nd}",
+                 f"s_and_b64 {S_T1}, vcc, {op('ex_if_back')}", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
+                 f"s_andn2_b64 {S_T1}, {op('ex_if_front')}, vcc", f"s_and_b64 {S_T1}, {S_T1}, {S_T2}", f"s_andn2_b64 {S_ALIVE}, {S_ALIVE}, {S_T1}",
+                 f"s_branch .Lcast_excl{buf}_back_%=",
+                 # A triangle on the previous triangle's plane.  Bit 30: its n and d equal the predecessor's only up to the
+                 # signs of zero components ((-0, 1, 0) after (0, 1, 0): the two halves of most square()s).  Every product and sum
+                 # the plane part forms is then the same too, except where ALL its terms are zeros: n.d = +-0 (t = +-inf or NaN, which
+                 # the reference keeps apart) — or num = +-0, i.e. t = +-0, rejected by `t <= 0` either way.  So if any lane has
+                 # n.d == 0 the triangle evaluates its own plane after all; otherwise the predecessor's values ARE its values.
+                 f".Lcast_follow{buf}_%=:",
+                 f"s_bitcmp1_b32 {T['obj']}, 30", f"s_cbranch_scc0 .Lcast_share{buf}_%=",
+                 f"v_cmp_eq_f32 vcc, 0, {nd}", f"s_and_b64 {S_T1}, vcc, exec", f"s_cbranch_scc1 .Lcast_lead{buf}_%=",
+                 # nothing to do unless some lane passed culling and t > 0 on the plane
+                 f".Lcast_share{buf}_%=:",
+                 f"s_cmp_lg_u64 {S_PLANE}, 0", f"s_cbranch_scc1 .Lcast_tri{buf}_%=", f"s_branch {label_next}"]
     w = (r[3], r[4], r[5])
+    L += cnt(7) if COUNT else []
     if SPHERE_FILTER:
         # Conservative rejection (rt_device_scene.h "bounding sphere"): the plane hit point p of a lane lies outside the
         # triangle for sure when q = |p - c|^2 exceeds bq = 1.05 R^2 (c, R: the triangle's enclosing circle) — at least one
@@ -182,41 +199,17 @@ def test(buf, label_next):
               f".Lcast_nofilter{buf}_%=:"]
     e0 = (T["e0x"], T["e0y"], T["e0z"]); e1 = (T["e1x"], T["e1y"], T["e1z"]); e2 = (T["e2x"], T["e2y"], T["e2z"])
     v0 = (T["v0x"], T["v0y"], T["v0z"]); v1 = (T["v1x"], T["v1y"], T["v1z"]); v2 = (T["v2x"], T["v2y"], T["v2z"])
-    if ILP:
-        # p = o + d*t was emitted component by component above; the three areas are independent chains: give each
-        # its own temporaries and issue them round-robin so a lone wave always has an independent instruction next
-        chains = [
-            area(r[6], e0, v1, p, (XT[0], XT[1], XT[2]), (r[6], XT[3], XT[4]), XT[5], n),
-            area(r[7], e1, v2, p, (XT[6], XT[7], XT[8]), (r[7], XT[9], XT[10]), XT[11], n),
-            area(r[8], e2, v0, p, (XT[12], XT[13], XT[14]), (r[8], XT[15], XT[16]), XT[17], n),
-        ]
-        for k in range(len(chains[0])):
-            for c in chains:
-                L.append(c[k])
-        L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
-    else:
-        # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
-        # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
-        early = EARLY_AREA_EXITS
-        L += cnt(3)
-        L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
-        if early:
-            L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
-        L += cnt(4)
-        L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
-        if early:
-            L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
-        L += cnt(5)
-        L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
-        if early:
-            L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
-        else:
-            L += [f"v_min3_f32 {r[9]}, {r[6]}, {r[7]}, {r[8]}", f"v_cmp_ngt_f32 vcc, 0, {r[9]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc"]
-    if NEAREST_EARLY:
-        L += [f"s_cbranch_scc0 {label_next}"]
-    else:
-        # nearest: !(best_t < t), best_t = NaN while None (main.rs:229-233)
-        L += [f"v_cmp_nlt_f32 vcc, {op('best_t')}, {t}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    # the three signed areas, each followed by its own wave-level exit: a lane stays alive unless its area < 0
+    # (v_cmp_ngt 0, a  ==  !(a < 0): NaN passes, main.rs:224); coherent waves usually leave after the first
+    L += cnt(3)
+    L += area(r[6], e0, v1, p, w, (r[6], r[9], r[10]), r[11], n)
+    L += [f"v_cmp_ngt_f32 vcc, 0, {r[6]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    L += cnt(4)
+    L += area(r[7], e1, v2, p, w, (r[7], r[9], r[10]), r[11], n)
+    L += [f"v_cmp_ngt_f32 vcc, 0, {r[7]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
+    L += cnt(5)
+    L += area(r[8], e2, v0, p, w, (r[8], r[9], r[10]), r[11], n)
+    L += [f"v_cmp_ngt_f32 vcc, 0, {r[8]}", f"s_and_b64 {S_ALIVE}, {S_ALIVE}, vcc", f"s_cbranch_scc0 {label_next}"]
     # accept for the lanes in alive
     L += cnt(6)
     L += [f"s_mov_b64 {S_EXSAVE}, exec", f"s_mov_b64 exec, {S_ALIVE}",
@@ -228,23 +221,26 @@ def test(buf, label_next):
 
 def main():
     L = []
-    L += [f"s_mov_b64 {S_PTR}, {op('ptr')}", f"s_mov_b32 {S_N}, {op('n')}", f"s_mov_b32 {S_I}, 0",
-          f"s_cmp_eq_u32 {S_N}, 0", "s_cbranch_scc1 .Lcast_done_%="]
+    N = op("n")
+    L += [f"s_mov_b32 {S_OFF}, 0", f"s_mov_b32 {S_I}, 0", f"s_mov_b64 {S_PLANE}, 0",
+          f"s_cmp_eq_u32 {N}, 0", "s_cbranch_scc1 .Lcast_done_%="]
     L += loads("A", 0)
+    # whatever its record says, the first triangle of a call has no predecessor in registers: it is a leader
+    L += ["s_waitcnt lgkmcnt(0)", f"s_bitset0_b32 {regs('A')['obj']}, 31"]
     L += [".Lcast_loop_%=:", "s_waitcnt lgkmcnt(0)"]
     L += loads("B", 0x80)
     L += test("A", ".Lcast_nextA_%=")
-    L += [".Lcast_nextA_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_ge_u32 {S_I}, {S_N}", "s_cbranch_scc1 .Lcast_done_%=",
-          "s_waitcnt lgkmcnt(0)", f"s_add_u32 {S_PTR_LO}, {S_PTR_LO}, 0x100", f"s_addc_u32 {S_PTR_HI}, {S_PTR_HI}, 0"]
+    L += [".Lcast_nextA_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_ge_u32 {S_I}, {N}", "s_cbranch_scc1 .Lcast_done_%=",
+          "s_waitcnt lgkmcnt(0)", f"s_add_u32 {S_OFF}, {S_OFF}, 0x100"]
     L += loads("A", 0)
     L += test("B", ".Lcast_nextB_%=")
-    L += [".Lcast_nextB_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_lt_u32 {S_I}, {S_N}", "s_cbranch_scc1 .Lcast_loop_%=",
+    L += [".Lcast_nextB_%=:", f"s_add_u32 {S_I}, {S_I}, 1", f"s_cmp_lt_u32 {S_I}, {N}", "s_cbranch_scc1 .Lcast_loop_%=",
           "s_branch .Lcast_done_%="]
     for b in ("A", "B"):
         L += SLOW.get(b, [])
     L += [".Lcast_done_%=:", "s_waitcnt lgkmcnt(0)"]
 
-    clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"] + (XT[:18] if ILP else [])
+    clobbers = [f"s{k}" for k in range(34, 100)] + ["vcc", "scc"]
     print("/* GENERATED by tools/gen_cast_asm.py — do not edit; edit the generator. */")
     print("#ifndef RT_CAST_ASM_H")
     print("#define RT_CAST_ASM_H")
