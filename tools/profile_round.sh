@@ -1,0 +1,22 @@
+#!/bin/bash
+# Evidence for a round (run on the GPU box): tools/profile_round.sh r02  ->  gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
+#   bench line, rocprofv3 kernel stats of the same command, PMC passes (separate, as MI355X_MICROARCH.md prescribes) for the
+#   Whitted kernel and for the stochastic pass's kernels, the workgroup phase timeline (diagnostic build, if present)
+set -e
+TAG=${1:-round}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
+python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/${TAG}_stats.log 2>&1
+cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc/$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stochastic > $O/${TAG}_pmc.$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_dist/$tag -- python3 $R/tools/bench_distributed.py --epochs 64 --calls 1 > $O/${TAG}_pmc_dist.$tag.log 2>&1
+done
+cd $R
+{ echo "# rocprofv3 --pmc (separate passes), bench.py --steps 5 --warmup 1, 1920x1080 depth 8: mean over the dispatches of rt::pwf_kernel; FETCH_SIZE / WRITE_SIZE in KB"; python3 tools/pmc_summary.py $O/${TAG}_pmc --kernel pwf_kernel; } > $O/${TAG}_pwf_pmc.txt
+{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 64 --calls 1 (configs[3]: 64 epochs from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB"
+  for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_dist --kernel $k; done; } > $O/${TAG}_dist_pmc.txt
+if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_pastats.so ]; then python3 tools/diag_pwf.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pwf_phases.txt; fi
+rm -rf $O/${TAG}_stats $O/${TAG}_pmc $O/${TAG}_pmc_dist $O/${TAG}_pmc.*.log $O/${TAG}_pmc_dist.*.log
