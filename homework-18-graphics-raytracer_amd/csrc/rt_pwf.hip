@@ -95,15 +95,9 @@ namespace rt {
                        * frame against 1.28 ms (profiles/README.md, round 2): the sixth field costs more than the arithmetic saves */
 #endif
 #define PA_SHADE_U4 (PA_SHADE_DL ? 6u : 5u) /* uint4s per SHADE item */
-#define PA_SEALED 0x80000000u
 #define PA_SPIN_LIMIT (1u << 22)
 
 enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u };
-
-struct PaQueue {
-    uint32_t alloc; /* next position to reserve */
-    uint32_t taken; /* next PAGE to claim */
-};
 
 struct PaShared {
     PaQueue n, f, s;          /* NODE (positions are node ids), REFR ring, SHADE ring */
@@ -123,60 +117,6 @@ struct PaShared {
 __device__ unsigned long long pa_phase_stats[32];
 #define PA_TICK() __builtin_readcyclecounter()
 #endif
-
-/* Items and records are stored field-major within pages of 64: field f of entry e sits at ((e >> 6) * F + f) * 64 + (e & 63)
- * (in uint4s).  The 64 lanes of a chunk hold 64 consecutive entries, so every load and store of a field is one contiguous
- * kilobyte (16 cache lines) instead of 64 pieces a record apart (64 lines): the queues' traffic is the same, the number of
- * lines the vector-memory pipeline touches a quarter.  pa_entry() returns the address of field 0; field f is 64 * f further. */
-#define PA_F(f) ((f) * 64u)
-__device__ __forceinline__ size_t pa_entry(uint32_t e, uint32_t fields) { return ((size_t)(e >> 6) * fields << 6) + (e & 63u); }
-
-__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-/* lane 0 only.  Try to claim the next page of a queue; on success *start is its first position and the return value its
- * item count.  ready[] holds one word per page (index masked for the rings). */
-__device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
-    for (int tries = 0; tries < 4; ++tries) {
-        const uint32_t page = lds_load(&q->taken);
-        const uint32_t a = lds_load(&q->alloc);
-        if (a <= page * 64u) return 0u; /* empty */
-        const uint32_t w = lds_load(&ready[page & page_mask]);
-        const uint32_t c = w & 0xffffu;
-        if (c == 64u || (w & PA_SEALED) != 0u) {
-            if (atomicCAS(&q->taken, page, page + 1u) == page) {
-                ready[page & page_mask] = 0u; /* the slot is reused one lap later at the earliest */
-                *start = page * 64u;
-                return c;
-            }
-            continue; /* somebody else took it: look at the next page */
-        }
-        if (min_partial == 0u || a >= (page + 1u) * 64u || c < min_partial || c != a - page * 64u) return 0u; /* still filling */
-        /* a partly filled last page whose reserved positions are all written: close it against further reservations */
-        if (atomicCAS(&q->alloc, a, (page + 1u) * 64u) == a) atomicOr(&ready[page & page_mask], PA_SEALED);
-    }
-    return 0u;
-}
-
-/* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
-__device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0ull) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the items are written before they are counted */
-    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
-    const int leader = (int)__builtin_ctzll(mask);
-    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader); /* the leader holds the lowest position */
-    if ((int)(threadIdx.x & 63u) == leader) {
-        const uint32_t p0 = first >> 6, p1 = (first + n - 1u) >> 6;
-        if (p0 == p1) {
-            atomicAdd(&ready[p0 & page_mask], n);
-        } else {
-            const uint32_t n0 = (p1 << 6) - first;
-            atomicAdd(&ready[p0 & page_mask], n0);
-            atomicAdd(&ready[p1 & page_mask], n - n0);
-        }
-        atomicAdd(gen, 1u); /* wakes the sleepers */
-    }
-}
 
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read once per tile, and as a
  * by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */

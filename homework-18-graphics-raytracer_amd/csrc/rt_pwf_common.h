@@ -46,6 +46,72 @@ __device__ __forceinline__ void pw_slot_to_pixel(const KernelFrame &fr, uint32_t
     *row = (band << 3) + (r - *col * band_rows);
 }
 
+/* ---- workgroup-local queues of work items (used by rt_pwf.hip and by the queued chain kernel of rt_distributed.hip) ----
+ * Positions are reserved with one wave-aggregated atomic on `alloc` (lds_append), the items are written, and then counted
+ * into `ready[page]` (pa_publish); consumers claim whole pages of 64 positions in order (pa_claim), full or — once nothing
+ * fuller is to be had — SEALED: `alloc` is moved to the page boundary by compare-and-swap so that no reservation can slip
+ * in, and the page is taken with the items it has.  All bookkeeping is in LDS; see the header of rt_pwf.hip. */
+#define PA_SEALED 0x80000000u
+struct PaQueue {
+    uint32_t alloc; /* next position to reserve */
+    uint32_t taken; /* next PAGE to claim */
+};
+
+
+/* Items and records are stored field-major within pages of 64: field f of entry e sits at ((e >> 6) * F + f) * 64 + (e & 63)
+ * (in uint4s).  The 64 lanes of a chunk hold 64 consecutive entries, so every load and store of a field is one contiguous
+ * kilobyte (16 cache lines) instead of 64 pieces a record apart (64 lines): the queues' traffic is the same, the number of
+ * lines the vector-memory pipeline touches a quarter.  pa_entry() returns the address of field 0; field f is 64 * f further. */
+#define PA_F(f) ((f) * 64u)
+__device__ __forceinline__ size_t pa_entry(uint32_t e, uint32_t fields) { return ((size_t)(e >> 6) * fields << 6) + (e & 63u); }
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+/* lane 0 only.  Try to claim the next page of a queue; on success *start is its first position and the return value its
+ * item count.  ready[] holds one word per page (index masked for the rings). */
+__device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
+    for (int tries = 0; tries < 4; ++tries) {
+        const uint32_t page = lds_load(&q->taken);
+        const uint32_t a = lds_load(&q->alloc);
+        if (a <= page * 64u) return 0u; /* empty */
+        const uint32_t w = lds_load(&ready[page & page_mask]);
+        const uint32_t c = w & 0xffffu;
+        if (c == 64u || (w & PA_SEALED) != 0u) {
+            if (atomicCAS(&q->taken, page, page + 1u) == page) {
+                ready[page & page_mask] = 0u; /* the slot is reused one lap later at the earliest */
+                *start = page * 64u;
+                return c;
+            }
+            continue; /* somebody else took it: look at the next page */
+        }
+        if (min_partial == 0u || a >= (page + 1u) * 64u || c < min_partial || c != a - page * 64u) return 0u; /* still filling */
+        /* a partly filled last page whose reserved positions are all written: close it against further reservations */
+        if (atomicCAS(&q->alloc, a, (page + 1u) * 64u) == a) atomicOr(&ready[page & page_mask], PA_SEALED);
+    }
+    return 0u;
+}
+
+/* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
+__device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the items are written before they are counted */
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const int leader = (int)__builtin_ctzll(mask);
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader); /* the leader holds the lowest position */
+    if ((int)(threadIdx.x & 63u) == leader) {
+        const uint32_t p0 = first >> 6, p1 = (first + n - 1u) >> 6;
+        if (p0 == p1) {
+            atomicAdd(&ready[p0 & page_mask], n);
+        } else {
+            const uint32_t n0 = (p1 << 6) - first;
+            atomicAdd(&ready[p0 & page_mask], n0);
+            atomicAdd(&ready[p1 & page_mask], n - n0);
+        }
+        atomicAdd(gen, 1u); /* wakes the sleepers */
+    }
+}
+
 /* get_shade's `for light in &self.lights` up to the next shadow cast (main.rs:413-433): advance *light_i to the first
  * light from *light_i on that needs one; false when the loop is over */
 __device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t *light_i, V3 pos, V3 adj_n, DirLight *dl) {
