@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--variant", type=int, default=None, help="kernel variant (include/rt_amd.h): 18 = persistent workgroup-local wavefronts (default); per-pixel kernel: bit 0 LDS broadcast (else SGPR), bits 1-2: 0 cost-sorted tiles, 2 static tiles, 4 persistent lanes, 6 two-phase; 8 cooperative")
+    p.add_argument("--variant", type=int, default=None, help="render path (include/rt_amd.h): 18 = the persistent wavefront kernel (default); 2 = the per-pixel kernel (scalar triangle fetches), 3 = with its triangle records staged in LDS; 19 = 18 with 3 as its fallback")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
@@ -349,8 +349,7 @@ def main() -> int:
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
                 "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame's rendering" if distributed else ""),
-                "kernel_variant": "persistent-wavefront" if variant & 16 else
-                                  ("lds" if variant & 1 else "sgpr") + "+" + ("cooperative" if variant & 8 else {0: "cost-sorted-tiles", 2: "static-tiles", 4: "persistent-lanes", 6: "two-phase"}[variant & 6]),
+                "kernel_variant": "persistent-wavefront" if variant & 16 else ("per-pixel, LDS-staged triangles" if variant & 1 else "per-pixel, scalar triangle fetches"),
             },
             "casts_per_frame": casts_per_frame,
             "casts_per_pixel": round(casts_per_frame / (W * H), 3),
@@ -363,7 +362,7 @@ def main() -> int:
                 "traffic": traffic,
                 "executed_valu": executed,
                 "kernel": "rt::pwf_kernel (the persistent render kernel; its two one-thread bookkeeping launches are in call_ms_avg)" if variant & 16
-                          else "rt::whitted_kernel<8, false, 0> (the render launch; the probe launch of the same call is in call_ms_avg)",
+                          else "rt::whitted_kernel<8, %s>" % ("true" if variant & 1 else "false"),
                 "kernel_ms_avg": round(kernel_ms_max, 4),
                 "call_ms_avg": round(call_ms, 4),
                 "flop_per_cast": flop_per_cast,

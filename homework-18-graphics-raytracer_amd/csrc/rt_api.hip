@@ -33,15 +33,10 @@ namespace rt {
 void math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
 }
 
-/* Per-(scene, stream) scratch: the two queue counters and the continuation buffer of the two-phase
- * scheme.  Launches on one stream are ordered, so they can share it; other streams get their own.
- * Grow-only; allocated on the first call that needs it (not inside a graph capture). */
+/* Per-(scene, stream) scratch.  Launches on one stream are ordered, so they can share it; other streams get
+ * their own.  Grow-only; allocated on the first call that needs it (not inside a graph capture). */
 struct Workspace {
-    uint32_t *d_counters = nullptr; /* [0] chunk counter, [1] continuation count */
-    uint32_t *d_cont = nullptr;
-    size_t cont_bytes = 0;
-    uint32_t *d_tiles = nullptr; /* RT_PROBE_CLASSES lists of tiles_n chunk ids */
-    size_t tiles_n = 0;
+    uint32_t *d_counters = nullptr; /* [0] the stochastic pass's chunk counter */
     void *d_pwf = nullptr; /* persistent-wavefront path: global words + one arena per workgroup */
     size_t pwf_bytes = 0;
     void *d_split = nullptr; /* split distributed pass: requests, shades and frames of one batch of epochs */
@@ -62,7 +57,6 @@ struct rt_scene {
 
 /* Process-wide settings (rt_set_*): read by render calls on any thread, so they are atomics.  A value < 0 means "not set
  * yet": the first reader resolves it from the environment (two threads doing that at once compute the same value). */
-static std::atomic<int> g_evict_threshold{-1}, g_evict_min_iter{-1};
 static std::atomic<int> g_wf_nodes_per_pixel{-1};
 static std::atomic<const uint32_t *> g_diag_tile_order{nullptr};
 #ifndef RT_DIST_SPLIT_DEFAULT
@@ -95,12 +89,14 @@ static int fail_hip(const char *what, hipError_t e) {
         if (e_ != hipSuccess) return fail_hip(#call, e_);     \
     } while (0)
 
+/* 2 / 3: the per-pixel kernel with scalar / LDS triangle fetches; 18 / 19: the persistent wavefront kernel (with that as its fallback) */
+static bool variant_ok(int v) { return v == 2 || v == 3 || v == 18 || v == 19; }
 static int current_variant() {
     int v = g_variant.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("RT_AMD_VARIANT");
         v = (e && *e) ? atoi(e) : RT_VARIANT_DEFAULT;
-        if (v < 0 || v > RT_VARIANT_MAX) v = RT_VARIANT_DEFAULT;
+        if (!variant_ok(v)) v = RT_VARIANT_DEFAULT;
         g_variant.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -146,7 +142,7 @@ int rt_set_device(int device) {
 }
 
 int rt_set_variant(int variant) {
-    if (variant < 0 || variant > RT_VARIANT_MAX) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: variant out of range");
+    if (!variant_ok(variant)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_variant: 2, 3, 18 or 19 (include/rt_amd.h)");
     g_variant.store(variant);
     return RT_OK;
 }
@@ -190,13 +186,6 @@ int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches) {
     *kernel_ms_sum = sum;
     *n_launches = (unsigned)g_prof_used;
     g_prof_used = 0;
-    return RT_OK;
-}
-
-int rt_set_eviction(int threshold, int min_iterations) {
-    if (threshold < 0 || threshold > 63 || min_iterations < 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_eviction: threshold 0..63, min_iterations >= 0");
-    g_evict_threshold.store(threshold);
-    g_evict_min_iter.store(min_iterations);
     return RT_OK;
 }
 
@@ -479,8 +468,6 @@ int rt_scene_destroy(rt_scene *scene) {
     hipError_t e = hipSuccess;
     for (auto &kv : scene->workspaces) {
         if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
-        if (kv.second.d_cont) (void)hipFree(kv.second.d_cont);
-        if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
         if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
         if (kv.second.d_split) (void)hipFree(kv.second.d_split);
         if (kv.second.d_chainq) (void)hipFree(kv.second.d_chainq);
@@ -539,52 +526,13 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);
     uint32_t pw_groups = 0, pw_band_rows = 0;
-    int evict_threshold = g_evict_threshold.load(), evict_min_iter = g_evict_min_iter.load();
-    if (evict_threshold < 0) {
-        const char *v = getenv("RT_AMD_EVICT_THRESHOLD");
-        evict_threshold = (v && *v) ? atoi(v) : 16;
-        if (evict_threshold < 0 || evict_threshold > 63) evict_threshold = 16;
-        const char *m = getenv("RT_AMD_EVICT_MIN_ITER");
-        evict_min_iter = (m && *m) ? atoi(m) : 4;
-        if (evict_min_iter < 0) evict_min_iter = 4;
-        g_evict_threshold.store(evict_threshold);
-        g_evict_min_iter.store(evict_min_iter);
-    }
     rt::KernelQueues qs;
     memset(&qs, 0, sizeof qs);
-    qs.evict_threshold = (uint32_t)evict_threshold;
-    qs.evict_min_iterations = (uint32_t)evict_min_iter;
     {
         rt_scene *mut = const_cast<rt_scene *>(scene); /* workspaces are the only mutable part of a scene */
         std::lock_guard<std::mutex> lock(mut->ws_mutex);
         Workspace &ws = mut->workspaces[stream];
         if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
-        if ((variant & RT_VARIANT_SCHEME_MASK) == RT_VARIANT_TWO_PHASE) {
-            /* a wave evicts at most evict_threshold lanes, once */
-            const uint64_t chunks = ((uint64_t)kf.cols * kf.rows + 63u) / 64u;
-            const uint64_t capacity = chunks * (qs.evict_threshold ? qs.evict_threshold : 1u);
-            const size_t need = (size_t)capacity * rt::cont_record_dwords(kf.max_depth) * sizeof(uint32_t);
-            if (need > ws.cont_bytes) {
-                if (ws.d_cont) (void)hipFree(ws.d_cont);
-                ws.d_cont = nullptr;
-                ws.cont_bytes = 0;
-                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_cont), need));
-                ws.cont_bytes = need;
-            }
-            qs.cont_buf = ws.d_cont;
-            qs.cont_capacity = (uint32_t)(capacity > 0xffffffffull ? 0xffffffffull : capacity);
-        }
-        if ((variant & RT_VARIANT_SCHEME_MASK) == RT_VARIANT_SORTED) {
-            const size_t chunks = (size_t)(((uint64_t)kf.cols * kf.rows + 63u) / 64u);
-            if (chunks > ws.tiles_n) {
-                if (ws.d_tiles) (void)hipFree(ws.d_tiles);
-                ws.d_tiles = nullptr;
-                ws.tiles_n = 0;
-                RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_tiles), (size_t)RT_PROBE_CLASSES * chunks * sizeof(uint32_t)));
-                ws.tiles_n = chunks;
-            }
-            qs.tile_order = ws.d_tiles;
-        }
         if (variant & RT_VARIANT_PWF) {
             /* The kernel keeps one LDS word per 64 ring slots and per 64 nodes, so an arena holds 64 K ring slots at most.
              * A tile too large for that at the budget asked for (beyond ~8 Mpixel at 6 nodes per pixel) is rendered as
@@ -635,9 +583,6 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 256;
             pw_groups = (uint32_t)groups;
         }
-        qs.work_queue = ws.d_counters;
-        qs.cont_count = ws.d_counters + 1;
-        qs.class_count = ws.d_counters + 2;
 #ifdef RT_DIAG_TIMELINE
         qs.timeline = g_diag_timeline;
 #endif
@@ -655,8 +600,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     } else {
         rt::set_main_kernel_events(nullptr, nullptr);
     }
-    hipError_t e = hipMemsetAsync(qs.work_queue, 0, (2 + RT_PROBE_CLASSES) * sizeof(uint32_t), stream);
-    if (e == hipSuccess && (variant & RT_VARIANT_PWF)) {
+    hipError_t e = hipSuccess;
+    if (variant & RT_VARIANT_PWF) {
         /* a band that does not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
         qs.run_if = pw.global + PW_G_OVERFLOW;
         for (uint32_t r0 = 0; e == hipSuccess && r0 < kf.rows; r0 += pw_band_rows) {
@@ -676,14 +621,14 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             e = rt::launch_pwf(scene->ks, band, band_rgb, d_ray_count, pw, pw_groups, stream, first, last);
             if (e == hipSuccess) {
                 rt::mute_main_kernel_events(true); /* the event pair brackets the persistent kernel(s), not the fallback */
-                e = rt::launch_whitted(scene->ks, band, band_rgb, d_ray_count, qs, scene->resident_waves, stream, RT_VARIANT_SGPR | RT_VARIANT_STATIC);
+                e = rt::launch_whitted(scene->ks, band, band_rgb, d_ray_count, qs, stream, (variant & RT_VARIANT_LDS) | RT_VARIANT_STATIC);
                 rt::mute_main_kernel_events(false);
             }
         }
         if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
         return RT_OK;
     }
-    if (e == hipSuccess) e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, scene->resident_waves, stream, variant);
+    e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, stream, variant);
     if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
     return RT_OK;
 }

@@ -24,20 +24,14 @@
 #endif
 #define RT_LDS_SCENE_LIMIT (96u * 1024u) /* triangle records staged in LDS up to this many bytes */
 
-/* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant) */
+/* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant): 2, 3, 18 (default), 19 */
 #define RT_VARIANT_SGPR 0 /* triangle records fetched with wave-uniform scalar loads */
-#define RT_VARIANT_LDS 1          /* bit 0: triangle records staged in LDS once per workgroup */
-#define RT_VARIANT_SCHEME_MASK 6  /* bits 1-2: how pixels reach lanes */
-#define RT_VARIANT_SORTED 0       /*   one 8x8 tile per wave, tiles dispatched most-expensive-first (cost probe + class lists) */
-#define RT_VARIANT_STATIC 2       /*   one 8x8 tile per wave in image order (as fast as SORTED once the probe is paid for) */
-#define RT_VARIANT_PERSISTENT 4   /*   lanes refill pixel by pixel from a global queue */
-#define RT_VARIANT_TWO_PHASE 6    /*   tiles that evict their last few lanes + a packed second pass */
-#define RT_VARIANT_COOP 8         /* bit 3: cooperative workgroups — four waves split every tile's triangle loop */
+#define RT_VARIANT_LDS 1          /* bit 0 (per-pixel kernel): triangle records staged in LDS once per workgroup */
+#define RT_VARIANT_STATIC 2       /* bit 1, always set: the per-pixel kernel renders one 8x8 tile per wave in image order (the bits round 1
+                                   * used for its other per-pixel schemes — values 0, 4, 6, 8 — are no longer accepted) */
 #define RT_VARIANT_PWF 16         /* bit 4: one persistent kernel of workgroup-local wavefronts (rt_pwf.hip, the default); a frame that
-                                   * does not fit its arenas is rendered by the per-pixel kernel on static tiles */
-#define RT_VARIANT_MAX 31
+                                   * does not fit its arenas is rendered by the per-pixel kernel */
 #define RT_VARIANT_DEFAULT (RT_VARIANT_PWF | RT_VARIANT_SGPR | RT_VARIANT_STATIC)
-#define RT_PROBE_CLASSES 32u /* upper bound on RT_PROBE_ITERS + 2 */
 
 namespace rt {
 
@@ -71,27 +65,18 @@ struct KernelFrame {
     float cam_origin_focus[3]; /* center + normalize(normalize(toward)) * near: shoot_focus normalises twice (main.rs:119) */
 };
 
-/* device-side queues of one launch */
+/* what a launch of the per-pixel kernel is told besides the scene and the frame */
 struct KernelQueues {
-    uint32_t *work_queue;          /* chunk counter (zeroed per launch) */
-    uint32_t *cont_count;          /* number of evicted lane states (zeroed per launch) */
-    uint32_t *cont_buf;            /* cont_capacity records of cont_record_dwords(max_depth) dwords */
-    uint32_t cont_capacity;
-    uint32_t evict_threshold;      /* phase 1 leaves when at most this many lanes are still active ... */
-    uint32_t evict_min_iterations; /* ... and it has done at least this many casts */
-    uint32_t *class_count;         /* RT_PROBE_CLASSES counters (zeroed per launch): chunks filed under each cost class */
-    uint32_t *tile_order;          /* RT_PROBE_CLASSES lists of n_chunks chunk ids (RT_VARIANT_SORTED) */
     unsigned long long *timeline;  /* diagnostic builds (RT_DIAG_TIMELINE): 4 u64 per wave, else unused */
     const uint32_t *run_if;        /* when set: the kernel is a no-op unless *run_if != 0 (the persistent-wavefront path's overflow fallback) */
 };
 
-uint32_t cont_record_dwords(int32_t max_depth);
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hook, see rt_profile_* */
 void record_main_kernel_event(int which, hipStream_t stream);    /* 0: start, 1: stop; no-op when profiling is off */
 void mute_main_kernel_events(bool muted);                        /* launches in between are not the render kernel */
 
 hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *out, unsigned long long *ray_count,
-                          const KernelQueues &qs, uint32_t resident_waves, hipStream_t stream, int variant);
+                          const KernelQueues &qs, hipStream_t stream, int variant);
 
 /* persistent workgroup-local wavefronts (rt_pwf.hip) */
 #define PW_G_TILE 0u       /* next tile of the frame */

@@ -259,21 +259,16 @@ int rt_accumulator_resolve_device(const float *d_sum, const float *d_weight, siz
 
 /* ---- diagnostics ------------------------------------------------------------ */
 
-/* Kernel variant used by the render entry points of this process (bit field):
- *   bit 0     0: triangle records fetched with wave-uniform scalar loads (SGPR broadcast)
- *             1: triangle records staged in LDS once per workgroup (LDS broadcast)
- *   bits 1-2  0: one 8x8 tile per wave, tiles dispatched most-expensive-first: a probe follows one pixel
- *                per tile for a few casts and files the tile under a cost class
- *             2: one 8x8 tile per wave, dispatched in image order (default)
- *             4: persistent waves, lanes refill pixel by pixel from a work queue
- *             6: two-phase: tiles park their last few lanes in a queue, a second pass packs them 64 per wave
- *   bit 3     8: cooperative workgroups: 256-thread groups of four tiles whose four waves split every live
- *                tile's triangle loop (finished waves help the others); bits 1-2 are then ignored
- *   bit 4     16: persistent workgroup-local wavefronts (csrc/rt_pwf.hip): one kernel whose workgroups keep queues of
- *                single-cast work items (a ray_trace activation's own cast, one cast of get_refract, one shadow cast
- *                of get_shade) and fold the results bottom-up at the end; a frame that does not fit the arenas is
- *                rendered by the per-pixel kernel selected by the bits below.  Same results bit for bit.
- * Default 18 (16 | 2), or the value of the RT_AMD_VARIANT environment variable at load. */
+/* Which kernel renders the Whitted pass (process-wide; same results bit for bit):
+ *   18 (default)  the persistent wavefront kernel (csrc/rt_pwf.hip): one kernel whose workgroups keep queues of single-cast
+ *                 work items (a ray_trace activation's own cast, one cast of get_refract, one shadow cast of get_shade)
+ *                 and fold the results bottom-up at the end; a frame that does not fit its arenas is rendered by the
+ *                 per-pixel kernel (2) within the same call
+ *   2             the per-pixel kernel (csrc/rt_kernels.hip): one work-item per primary ray, a wave = an 8x8 tile, the
+ *                 recursion unrolled into a per-lane state machine; triangle records fetched with wave-uniform scalar loads
+ *   3, 19         as 2 / 18 with the per-pixel kernel's triangle records staged in LDS once per workgroup (the north_star's
+ *                 wording; slower than the scalar fetches: DESIGN.md, profiles/)
+ * or the value of the RT_AMD_VARIANT environment variable at load.  Anything else is RT_ERR_INVALID_ARGUMENT. */
 int rt_set_variant(int variant);
 int rt_get_variant(void);
 
@@ -288,15 +283,13 @@ int rt_set_wavefront_budget(unsigned nodes_per_pixel);
  *   1 (default)  three kernels per batch of epochs — the scatter chain with all random draws, every get_shade it
  *                asked for, the unwind + filter + accumulation — over a per-stream workspace (852 B per sample at depth 8,
  *                at most RT_AMD_DIST_WS_MB MiB, default 16384; a batch is as many epochs as fit, 16 at most, and fewer if the device
- *                cannot provide the memory — down to organisation 0 when not even one epoch fits);
+ *                cannot provide the memory — down to organisation 0 when not even one epoch fits; a workspace that holds at
+ *                least half the batch wanted is kept rather than replaced);
+ *   2            as 1 with the chain as a kernel of workgroup-local queues (every cast a work item, as in the Whitted path):
+ *                phase-coherent chunks, 1.1 GB more workspace; measured 3 % slower than 1;
  *   0            one kernel, a lane stays on its pixel through chain, shades and unwind (no workspace).
  * -1 restores the default / the RT_AMD_DIST_SPLIT environment variable. */
 int rt_set_distributed_split(int on);
-
-/* Two-phase (variant 6) tuning: a tile wave parks its remaining lanes once at most `threshold` (0..63) are active
- * and it has done at least `min_iterations` casts.  Defaults 16 / 4 (RT_AMD_EVICT_THRESHOLD,
- * RT_AMD_EVICT_MIN_ITER).  Changes scheduling only, never results. */
-int rt_set_eviction(int threshold, int min_iterations);
 
 /* Timing of the dominant (render) kernel alone: while enabled, each rt_render_whitted call records a HIP
  * event pair on its stream right around that kernel (a call may also launch a small probe kernel);

@@ -44,7 +44,7 @@ def test_argument_validation_returns_status():
     assert lib.rt_frame_pixels(C.byref(bad)) == 0
     good = rt.Frame.rows_of_rank(1920, 1080, 8, 3, 8)
     assert lib.rt_frame_rows(C.byref(good)) == 135 and lib.rt_frame_pixels(C.byref(good)) == 135 * 1920
-    assert lib.rt_set_variant(99) == -1 and lib.rt_set_eviction(64, 0) == -1
+    assert lib.rt_set_variant(99) == -1 and lib.rt_set_variant(0) == -1 and lib.rt_set_variant(6) == -1  # 2, 3, 18, 19 only
     # a tile of 2^32 pixels or more is refused, not wrapped (checked before any device work)
     huge = rt.Frame.full(65536, 65536, 5)
     h = C.c_void_p()

@@ -35,8 +35,8 @@ def test_random_scene_whitted(seed, nt, ns):
     _check(world, _scenes.camera(seed), rt.Frame.full(96, 64, 5))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 6, 8])
-def test_random_scene_all_schedulers(variant):
+@pytest.mark.parametrize("variant", [3, 18, 19])
+def test_random_scene_every_render_path(variant):
     world = _scenes.random_world(21, 40, 4)
     _check(world, _scenes.camera(21), rt.Frame.full(120, 90, 6), variant)
 
@@ -47,14 +47,9 @@ def test_deep_recursion_uses_the_large_stack_template(depth):
     _check(world, rt.reference_camera(), rt.Frame.full(80, 60, depth))
 
 
-@pytest.mark.parametrize("seed,nt,ns", [(31, 0, 2), (32, 1, 1), (33, 3, 0), (34, 5, 2), (35, 66, 3), (36, 131, 2)])
-def test_cooperative_cast_on_awkward_triangle_counts(seed, nt, ns):
-    """variant 8 splits the triangle loop four ways: counts below four, not divisible by four, above 64."""
-    world = _scenes.random_world(seed, nt, ns)
-    _check(world, _scenes.camera(seed), rt.Frame.full(72, 56, 6), 8)
-
-
-def test_cooperative_cast_with_nan_candidates_falls_back_to_the_sequential_scan():
+def test_nan_face_normal_is_accepted_as_the_reference_accepts_it():
+    """A degenerate (collinear) triangle has a NaN face normal: t = NaN passes `t <= 0`, NaN areas pass `< 0`, and NaN as the
+    nearest distance lets every later triangle through (main.rs:205, 224, 229-233) — the scan's history matters."""
     rng = np.random.default_rng(9)
     w = rt.World()
     o = w.push_object(_scenes.material(rng, "plain"))
@@ -62,7 +57,8 @@ def test_cooperative_cast_with_nan_candidates_falls_back_to_the_sequential_scan(
     for k in range(9):
         o.push_flat_triangle([(k * 0.3 - 1, 0.2, -1), (k * 0.3 - 1, 0.2, 1), (k * 0.3 - 0.8, 0.9, 0)], [(0, 0), (1, 0), (0, 1)])
     w.push_light(_scenes.light(rng, 2))
-    _check(w, rt.reference_camera(), rt.Frame.full(64, 48, 3), 8)
+    for variant in (2, 18):
+        _check(w, rt.reference_camera(), rt.Frame.full(64, 48, 3), variant)
 
 
 def test_empty_scene_renders_black():

@@ -29,7 +29,7 @@ ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--depth", type=int, default=8)
-ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--variant", type=int, default=18)
 ap.add_argument("--world", type=int, default=1, help="render only rank 0's interleaved row band of this many ranks (a multi-GPU share)")
 args = ap.parse_args()
 
@@ -40,9 +40,9 @@ desc = world.desc()
 frame = rt.Frame.full(args.width, args.height, args.depth) if args.world == 1 else rt.Frame.rows_of_rank(args.width, args.height, args.depth, 0, args.world)
 libs = {}
 for tag in args.tags.split(","):
-    parts = tag.split(":")  # "name", "name:variant", "name:variant:evict_threshold:evict_min_iter" or "name:variant:ENV=value[;ENV=value]"
+    parts = tag.split(":")  # "name", "name:variant" or "name:variant:ENV=value[;ENV=value]"
     name, var = parts[0], (parts[1] if len(parts) > 1 else "")
-    evict = (int(parts[2]), int(parts[3])) if len(parts) > 3 else None
+    evict = None
     env = dict(kv.split("=", 1) for kv in parts[2].split(";")) if len(parts) == 3 else {}
     for k in ENV_KNOBS:
         os.environ.pop(k, None)
@@ -68,8 +68,6 @@ def run(tag, n):
         os.environ.pop(k, None)
     os.environ.update(env)
     lib.rt_set_variant(lib_variant)
-    if evict is not None:
-        lib.rt_set_eviction(*evict)
     for _ in range(n):
         rc = lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(stream))
         assert rc == 0, lib.rt_last_error()
