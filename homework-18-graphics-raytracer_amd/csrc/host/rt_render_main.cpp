@@ -3,7 +3,7 @@
  * with the two rayon render loops replaced by calls across the C ABI.
  *
  *   rt_render [--width W] [--height H] [--depth D] [--obj dodecahedron.obj] [--out out.png] [--epochs N]
- *             [--focus F] [--blur B] [--scene in.rtscene] [--save-scene out.rtscene]
+ *             [--focus F] [--blur B] [--scene in.rtscene] [--save-scene out.rtscene] [--devices 0,1,...]
  *
  * Defaults are the reference's literals: 1280x960, depth 5 (main.rs:1084-1085, 1098).  --epochs N (default 0; the
  * reference: 100, main.rs:1129) continues as main() does: N epochs of the depth-of-field pass (shoot_focus(focus, blur),
@@ -12,6 +12,8 @@
  * report/out_small_blur.png (tests/test_gpu_reference_pins.py).
  * --scene renders a scene file (rt_world_load_scene; its camera if it carries one, else main()'s) instead of the literal
  * scene; --save-scene writes the scene in use (with the camera) as such a file before rendering.
+ * --devices renders on several GPUs from this one process (rt_multi_*: interleaved row bands, one per list entry; an index may
+ * repeat); without it the current device renders everything.
  * Host keeps: scene build + OBJ import, post_process, sRGB/u8 encode, PNG write.
  */
 #include <chrono>
@@ -29,6 +31,7 @@ int main(int argc, char **argv) {
     const char *obj = "dodecahedron.obj";
     const char *out = "./out.png";
     const char *scene_in = nullptr, *scene_out = nullptr;
+    std::vector<int> devices;
     int epochs = 0;
     float focus = 3.0f, blur = 0.04f; /* main.rs:1147-1148 */
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -40,6 +43,13 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--epochs")) epochs = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--scene")) scene_in = argv[i + 1];
         else if (!strcmp(argv[i], "--save-scene")) scene_out = argv[i + 1];
+        else if (!strcmp(argv[i], "--devices")) {
+            for (const char *c = argv[i + 1]; *c;) {
+                devices.push_back(atoi(c));
+                while (*c && *c != ',') ++c;
+                if (*c == ',') ++c;
+            }
+        }
         else if (!strcmp(argv[i], "--focus")) focus = strtof(argv[i + 1], nullptr);
         else if (!strcmp(argv[i], "--blur")) blur = strtof(argv[i + 1], nullptr);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
@@ -62,14 +72,21 @@ int main(int argc, char **argv) {
     rt_frame_full(width, height, depth, &frame);
 
     rt_scene *scene = nullptr;
-    if (rt_scene_create(&desc, &scene) != RT_OK) {
+    rt_multi *multi = nullptr;
+    if (!devices.empty()) {
+        if (rt_multi_create(&desc, devices.data(), (int)devices.size(), &multi) != RT_OK) {
+            fprintf(stderr, "rt_multi_create failed: %s\n", rt_last_error());
+            return 1;
+        }
+    } else if (rt_scene_create(&desc, &scene) != RT_OK) {
         fprintf(stderr, "rt_scene_create failed: %s\n", rt_last_error());
         return 1;
     }
     std::vector<float> img((size_t)width * height * 3);
     unsigned long long casts = 0;
     auto t0 = std::chrono::steady_clock::now();
-    if (rt_render_whitted_host(scene, &camera, &frame, img.data(), &casts) != RT_OK) {
+    if ((multi ? rt_multi_render_whitted_host(multi, &camera, &frame, img.data(), &casts)
+               : rt_render_whitted_host(scene, &camera, &frame, img.data(), &casts)) != RT_OK) {
         fprintf(stderr, "rt_render_whitted_host failed: %s\n", rt_last_error());
         return 1;
     }
@@ -87,14 +104,15 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (epochs > 0) {
-        rt_rng *rng = nullptr; /* main.rs:1117-1127 */
-        if (rt_rng_create(&frame, &rng) != RT_OK) {
+        rt_rng *rng = nullptr; /* main.rs:1117-1127 (rt_multi creates its generators on the first epoch) */
+        if (!multi && rt_rng_create(&frame, &rng) != RT_OK) {
             fprintf(stderr, "rt_rng_create failed: %s\n", rt_last_error());
             return 1;
         }
         for (int i = 0; i < epochs; ++i) {
             t0 = std::chrono::steady_clock::now();
-            if (rt_render_distributed_host(scene, &camera, &frame, focus, blur, rng, 1, img.data(), &casts) != RT_OK) {
+            if ((multi ? rt_multi_render_distributed_host(multi, &camera, &frame, focus, blur, 1, img.data(), &casts)
+                       : rt_render_distributed_host(scene, &camera, &frame, focus, blur, rng, 1, img.data(), &casts)) != RT_OK) {
                 fprintf(stderr, "rt_render_distributed_host failed: %s\n", rt_last_error());
                 return 1;
             }
@@ -109,6 +127,7 @@ int main(int argc, char **argv) {
         }
         rt_rng_destroy(rng);
     }
+    rt_multi_destroy(multi);
     rt_scene_destroy(scene);
     rt_world_free(world);
     return 0;

@@ -963,6 +963,225 @@ int rt_render_distributed_host(const rt_scene *scene, const rt_camera *camera, c
     return RT_OK;
 }
 
+/* ---- several devices from one process ------------------------------------------------
+ * The sharding of dist.py (interleaved row bands, the scene replicated, no data-path collective, one gather of
+ * the bands) for a host that is neither Python nor MPI: the Rust main() the boundary is designed for.  One scene copy, one
+ * stream and one band buffer per entry of `devices`; an entry may repeat (several bands on one GPU: how the one-GPU test
+ * box exercises this).  Bands are rendered concurrently, copied to pinned host memory and de-interleaved on the host —
+ * the destination is a host image anyway. */
+struct rt_multi {
+    struct Part {
+        int device = 0;
+        rt_scene *scene = nullptr;
+        hipStream_t stream = nullptr;
+        float *d_band = nullptr;
+        size_t band_floats = 0;
+        unsigned long long *d_count = nullptr;
+        float *h_band = nullptr; /* pinned */
+        size_t h_floats = 0;
+        rt_rng *rng = nullptr; /* stochastic pass: the streams of this part's rows */
+        rt_frame rng_frame;
+    };
+    std::vector<Part> parts;
+    rt_frame rng_for; /* the frame the generators were created for */
+    bool have_rng = false;
+};
+
+static void multi_part_frame(const rt_frame *f, int r, int n, rt_frame *out) {
+    *out = *f;
+    out->y0 = f->y0 + (uint32_t)r * f->y_step;
+    out->y_step = f->y_step * (uint32_t)n;
+}
+
+int rt_multi_destroy(rt_multi *m) {
+    if (!m) return RT_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (auto &p : m->parts) {
+        (void)hipSetDevice(p.device);
+        if (p.stream) (void)hipStreamSynchronize(p.stream);
+        if (p.rng) (void)rt_rng_destroy(p.rng);
+        if (p.scene) (void)rt_scene_destroy(p.scene);
+        if (p.d_band) (void)hipFree(p.d_band);
+        if (p.d_count) (void)hipFree(p.d_count);
+        if (p.h_band) (void)hipHostFree(p.h_band);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+    }
+    (void)hipSetDevice(prev);
+    delete m;
+    return RT_OK;
+}
+
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, rt_multi **out) {
+    if (!desc || !devices || !out || n_devices < 1) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_create: null argument or no devices");
+    *out = nullptr;
+    int n_visible = 0;
+    RT_HIP(hipGetDeviceCount(&n_visible));
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= n_visible) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_create: device index out of range");
+    rt_multi *m = new (std::nothrow) rt_multi();
+    if (!m) return fail(RT_ERR_OUT_OF_MEMORY, "rt_multi_create: host allocation failed");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    m->parts.resize((size_t)n_devices);
+    int rc = RT_OK;
+    for (int i = 0; i < n_devices && rc == RT_OK; ++i) {
+        rt_multi::Part &p = m->parts[(size_t)i];
+        p.device = devices[i];
+        hipError_t e = hipSetDevice(p.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p.d_count), sizeof(unsigned long long));
+        if (e != hipSuccess) { rc = fail_hip("rt_multi_create", e); break; }
+        rc = rt_scene_create(desc, &p.scene);
+    }
+    (void)hipSetDevice(prev);
+    if (rc != RT_OK) {
+        const std::string msg = g_error;
+        (void)rt_multi_destroy(m);
+        g_error = msg;
+        return rc;
+    }
+    *out = m;
+    return RT_OK;
+}
+
+/* band buffers of the parts for `frame` (grow-only); returns the rows of part r in rows_out[r] */
+static int multi_prepare(rt_multi *m, const rt_frame *frame, std::vector<rt_frame> *frames) {
+    const int n = (int)m->parts.size();
+    frames->resize((size_t)n);
+    for (int r = 0; r < n; ++r) {
+        rt_multi::Part &p = m->parts[(size_t)r];
+        multi_part_frame(frame, r, n, &(*frames)[(size_t)r]);
+        const rt_frame &pf = (*frames)[(size_t)r];
+        const size_t floats = pf.y0 < pf.y1 ? (size_t)rt_frame_pixels(&pf) * 3u : 0u;
+        RT_HIP(hipSetDevice(p.device));
+        if (floats > p.band_floats) {
+            if (p.d_band) (void)hipFree(p.d_band);
+            p.d_band = nullptr;
+            p.band_floats = 0;
+            RT_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_band), floats * sizeof(float)));
+            p.band_floats = floats;
+        }
+        if (floats > p.h_floats) {
+            if (p.h_band) (void)hipHostFree(p.h_band);
+            p.h_band = nullptr;
+            p.h_floats = 0;
+            RT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p.h_band), floats * sizeof(float), hipHostMallocDefault));
+            p.h_floats = floats;
+        }
+    }
+    return RT_OK;
+}
+
+/* image row k of the tile (k-th rendered row) belongs to part k % n, its row k / n */
+static void multi_deinterleave(const rt_multi *m, const rt_frame *frame, float *h_rgb) {
+    const size_t n = m->parts.size();
+    const size_t cols = frame->x1 - frame->x0;
+    const size_t rows = rt_frame_rows(frame);
+    for (size_t k = 0; k < rows; ++k) {
+        const rt_multi::Part &p = m->parts[k % n];
+        const float *src = p.h_band + (k / n) * cols * 3u;
+        float *dst = h_rgb + k * cols * 3u;
+        memcpy(dst, src, cols * 3u * sizeof(float));
+    }
+}
+
+int rt_multi_render_whitted_host(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float *h_rgb, unsigned long long *h_ray_count) {
+    if (!m || !camera || !h_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_whitted_host: null argument");
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_whitted_host: bad frame");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<rt_frame> frames;
+    int rc = multi_prepare(m, frame, &frames);
+    const int n = (int)m->parts.size();
+    for (int r = 0; r < n && rc == RT_OK; ++r) { /* every part's band is in flight before the first is waited for */
+        rt_multi::Part &p = m->parts[(size_t)r];
+        const rt_frame &pf = frames[(size_t)r];
+        hipError_t e = hipSetDevice(p.device);
+        if (e == hipSuccess) e = hipMemsetAsync(p.d_count, 0, sizeof(unsigned long long), p.stream);
+        if (e != hipSuccess) { rc = fail_hip("rt_multi_render_whitted_host", e); break; }
+        if (!(pf.y0 < pf.y1)) continue; /* more parts than rows */
+        rc = rt_render_whitted(p.scene, camera, &pf, p.d_band, p.d_count, p.stream);
+        if (rc == RT_OK) {
+            e = hipMemcpyAsync(p.h_band, p.d_band, (size_t)rt_frame_pixels(&pf) * 3u * sizeof(float), hipMemcpyDeviceToHost, p.stream);
+            if (e != hipSuccess) rc = fail_hip("rt_multi_render_whitted_host: copy", e);
+        }
+    }
+    unsigned long long total = 0;
+    for (int r = 0; r < n; ++r) {
+        rt_multi::Part &p = m->parts[(size_t)r];
+        (void)hipSetDevice(p.device);
+        hipError_t e = hipStreamSynchronize(p.stream);
+        unsigned long long c = 0;
+        if (e == hipSuccess) e = hipMemcpy(&c, p.d_count, sizeof c, hipMemcpyDeviceToHost);
+        if (e != hipSuccess && rc == RT_OK) rc = fail_hip("rt_multi_render_whitted_host: synchronize", e);
+        total += c;
+    }
+    (void)hipSetDevice(prev);
+    if (rc != RT_OK) return rc;
+    multi_deinterleave(m, frame, h_rgb);
+    if (h_ray_count) *h_ray_count = total;
+    return RT_OK;
+}
+
+int rt_multi_render_distributed_host(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float focus, float blur, uint32_t n_epochs,
+                                     float *h_accum, unsigned long long *h_ray_count) {
+    if (!m || !camera || !h_accum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_distributed_host: null argument");
+    if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_distributed_host: bad frame");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    std::vector<rt_frame> frames;
+    int rc = multi_prepare(m, frame, &frames);
+    const int n = (int)m->parts.size();
+    /* the generators: created on the first call for a frame and kept (the streams continue from call to call, main.rs:1131);
+     * a different frame starts new ones, as a new rt_rng_create would */
+    if (rc == RT_OK && (!m->have_rng || memcmp(&m->rng_for, frame, sizeof *frame) != 0)) {
+        for (int r = 0; r < n && rc == RT_OK; ++r) {
+            rt_multi::Part &p = m->parts[(size_t)r];
+            RT_HIP(hipSetDevice(p.device));
+            if (p.rng) { (void)rt_rng_destroy(p.rng); p.rng = nullptr; }
+            if (frames[(size_t)r].y0 < frames[(size_t)r].y1) rc = rt_rng_create(&frames[(size_t)r], &p.rng);
+        }
+        m->rng_for = *frame;
+        m->have_rng = rc == RT_OK;
+    }
+    const size_t cols = frame->x1 - frame->x0;
+    const size_t rows = rt_frame_rows(frame);
+    for (int r = 0; r < n && rc == RT_OK; ++r) {
+        rt_multi::Part &p = m->parts[(size_t)r];
+        const rt_frame &pf = frames[(size_t)r];
+        hipError_t e = hipSetDevice(p.device);
+        if (e == hipSuccess) e = hipMemsetAsync(p.d_count, 0, sizeof(unsigned long long), p.stream);
+        if (e != hipSuccess) { rc = fail_hip("rt_multi_render_distributed_host", e); break; }
+        if (!(pf.y0 < pf.y1)) continue;
+        /* img continues from the caller's sums: this part's rows of it, interleaved -> band */
+        for (size_t k = (size_t)r, b = 0; k < rows; k += (size_t)n, ++b) memcpy(p.h_band + b * cols * 3u, h_accum + k * cols * 3u, cols * 3u * sizeof(float));
+        const size_t bytes = (size_t)rt_frame_pixels(&pf) * 3u * sizeof(float);
+        e = hipMemcpyAsync(p.d_band, p.h_band, bytes, hipMemcpyHostToDevice, p.stream);
+        if (e != hipSuccess) { rc = fail_hip("rt_multi_render_distributed_host: upload", e); break; }
+        rc = rt_render_distributed(p.scene, camera, &pf, focus, blur, p.rng, n_epochs, p.d_band, nullptr, nullptr, p.d_count, p.stream);
+        if (rc == RT_OK) {
+            e = hipMemcpyAsync(p.h_band, p.d_band, bytes, hipMemcpyDeviceToHost, p.stream);
+            if (e != hipSuccess) rc = fail_hip("rt_multi_render_distributed_host: copy", e);
+        }
+    }
+    unsigned long long total = 0;
+    for (int r = 0; r < n; ++r) {
+        rt_multi::Part &p = m->parts[(size_t)r];
+        (void)hipSetDevice(p.device);
+        hipError_t e = hipStreamSynchronize(p.stream);
+        unsigned long long c = 0;
+        if (e == hipSuccess) e = hipMemcpy(&c, p.d_count, sizeof c, hipMemcpyDeviceToHost);
+        if (e != hipSuccess && rc == RT_OK) rc = fail_hip("rt_multi_render_distributed_host: synchronize", e);
+        total += c;
+    }
+    (void)hipSetDevice(prev);
+    if (rc != RT_OK) return rc;
+    multi_deinterleave(m, frame, h_accum); /* the bands hold img + samples */
+    if (h_ray_count) *h_ray_count = total;
+    return RT_OK;
+}
+
 /* ---- post_process / encode on the device ----------------------------------------- */
 
 struct PostWs {

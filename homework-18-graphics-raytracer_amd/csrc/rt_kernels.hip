@@ -170,7 +170,8 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
         }
         const unsigned long long active = __builtin_amdgcn_ballot_w64(phase != PH_DONE);
         if (active == 0ull) break;
-        iteration += 1u;
+        iteration += 1u; /* read by the RT_DIAG_TIMELINE build only */
+        (void)iteration;
         CastResult cr;
         cr.prim = -1;
         cr.t = 0.0f;

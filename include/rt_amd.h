@@ -236,6 +236,25 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
 int rt_render_distributed_host(const rt_scene *scene, const rt_camera *camera, const rt_frame *frame, float focus, float blur,
                                rt_rng *rng, uint32_t n_epochs, float *h_accum, unsigned long long *h_ray_count);
 
+/* ---- several GPUs from one process (SURVEY §8e without Python or MPI) -------------------
+ * Image rows are interleaved over the entries of `devices` exactly as homework-18-graphics-raytracer_amd/dist.py interleaves
+ * them over ranks (entry r renders rows y0 + r*y_step, y0 + (r+n)*y_step, ...): the scene is replicated, the bands are
+ * rendered concurrently, copied to pinned host memory and de-interleaved into the caller's image.  A device index may
+ * repeat (several bands on one GPU).  This is the form a single-process host — the reference's main() — binds to use a
+ * whole node; the one-process-per-GPU form over torch.distributed / RCCL is dist.py's.  Results are those of the
+ * single-device entry points bit for bit: a pixel's value, and its random stream (seeded by IMAGE coordinates), do not
+ * depend on which device renders it. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, rt_multi **out);
+int rt_multi_destroy(rt_multi *m);
+/* rt_render_whitted_host over the devices: h_rgb = rt_frame_pixels(frame) * 3 floats; *h_ray_count = casts of all devices. */
+int rt_multi_render_whitted_host(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float *h_rgb, unsigned long long *h_ray_count);
+/* rt_render_distributed_host over the devices.  The per-pixel generators live on the device that owns the pixel's row; they
+ * are created on the first call for a frame and continue from call to call (main.rs:1131); a call with a different frame
+ * starts new ones. */
+int rt_multi_render_distributed_host(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float focus, float blur, uint32_t n_epochs,
+                                     float *h_accum, unsigned long long *h_ray_count);
+
 /* ---- the step after the path, on the device --------------------
 
  * post_process (src/main.rs:748-762): divide the image in place by the 99th-percentile luma of its normal

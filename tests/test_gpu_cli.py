@@ -33,3 +33,18 @@ def test_rt_render_writes_the_same_png_as_the_python_mirror(tmp_path, epochs):
     want = tmp_path / "mirror.png"
     rt.write_to_file(str(want), rt.encode_srgb8(img))
     assert out.read_bytes() == want.read_bytes()
+
+
+def test_rt_render_on_a_device_list_writes_the_same_png(tmp_path):
+    """`--devices 0,0,0`: all of main() through rt_multi_* (three bands, three generator sets on the one GPU of the box) —
+    the PNG must be the single-device one byte for byte."""
+    w, h, depth, epochs = 200, 150, 5, 3
+    outs = []
+    for extra in ([], ["--devices", "0,0,0"]):
+        out = tmp_path / f"cli{len(extra)}.png"
+        cmd = [str(_capi.PKG_DIR / "rt_render"), "--width", str(w), "--height", str(h), "--depth", str(depth), "--obj", rt.DEFAULT_OBJ,
+               "--out", str(out), "--epochs", str(epochs)] + extra
+        done = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
