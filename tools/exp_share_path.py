@@ -47,6 +47,20 @@ for b0 in range(0, rows, 8):
     slot += block.size
 order = np.argsort(-cost, kind="stable").astype(np.uint32)
 d_order = torch.from_numpy(order.astype(np.int32)).cuda()
+# a proxy for the length of a tile's dependent chains rather than for its work: the casts that depth 8 adds to depth 2
+shallow = rt.Frame(frame.width, frame.height, 2, frame.x0, frame.y0, frame.x1, frame.y1, frame.y_step)
+cnt2 = np.zeros((rows, cols), np.uint32)
+img2 = np.zeros((rows, cols, 3), np.float32)
+ol.orc_render_whitted_counts(C.byref(desc), C.byref(cam), C.byref(shallow), img2.ctypes.data, cnt2.ctypes.data, 0)
+deep = np.zeros(n_tiles, np.int64)
+slot = 0
+for b0 in range(0, rows, 8):
+    br = min(8, rows - b0)
+    block = (cnt[b0:b0 + br].astype(np.int64) - cnt2[b0:b0 + br].astype(np.int64)).T.reshape(-1)
+    idx = (slot + np.arange(block.size)) // 64
+    np.maximum.at(deep, idx, block)  # the deepest PIXEL of the tile decides
+    slot += block.size
+d_deep = torch.from_numpy(np.argsort(-deep, kind="stable").astype(np.int32)).cuda()
 out = torch.empty((rows, cols, 3), dtype=torch.float32, device="cuda")
 print(f"share 1/{a.world}: {rows}x{cols} pixels, {n_tiles} tiles, casts {int(cnt.sum())}, deepest tile {int(cost.max())} casts, mean {cost.mean():.0f}")
 for tag in a.libs.split(","):
@@ -58,7 +72,7 @@ for tag in a.libs.split(","):
     h = C.c_void_p(); assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0
     lib.rt_set_variant(18)
     res = {}
-    for name, ptr in (("default order", None), ("deepest tiles first", d_order.data_ptr())):
+    for name, ptr in (("default order", None), ("most casts first", d_order.data_ptr()), ("longest chains first", d_deep.data_ptr())):
         lib.rt_diag_set_tile_order(C.c_void_p(ptr) if ptr else None)
         times = []
         for r in range(a.rounds + 2):
