@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -316,70 +317,153 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         /* 1.05 R^2, plus the float rounding of the centre (<= 1e-7 * extent per axis, far inside the margin), rounded up */
         t.bq = std::nextafter((float)(1.05 * r2 * 1.0001), std::numeric_limits<float>::infinity());
     }
-    /* the triangles as runs for the intersection loop; runs of one object's triangles become clusters (rt_device_scene.h) */
+    /* The triangles as NODES for the intersection loop (rt_device_scene.h "segments"): a pre-order array of leaves (runs of
+     * consecutive triangles) and inner nodes over them, each with a skip pointer.  A run of one object's >= 8 triangles, all of
+     * which qualify for their own bounding-sphere rejection, becomes a tree: leaves of RT_LEAF_TRIANGLES, grouped 16 by 16;
+     * every node that is small against the scene gets a bounding sphere and either up to 8 representative face normals or a
+     * normal cone, and can then be skipped by a wave none of whose rays can hit anything in it.  Everything else is a plain
+     * leaf that is always visited. */
     std::vector<rt::DevSegment> segments;
     {
         const bool clusters_off = filter_off || getenv("RT_AMD_NO_CLUSTERS") != nullptr; /* A/B switch; results are the same either way */
+        const bool flat_only = getenv("RT_AMD_NO_HIERARCHY") != nullptr; /* A/B: one cluster per object run, explicit normals only (round 1) */
         auto push_plain = [&](uint32_t first, uint32_t count) {
-            if (!segments.empty() && segments.back().n_normals == 0u && segments.back().first + segments.back().count == first) {
-                segments.back().count += count; /* adjacent plain runs are one segment */
+            if (!segments.empty() && segments.back().n_normals == 0u && segments.back().count != 0u &&
+                segments.back().first + segments.back().count == first) {
+                segments.back().count += count; /* adjacent plain runs are one leaf */
                 return;
             }
             rt::DevSegment g;
             memset(&g, 0, sizeof g);
             g.first = first;
             g.count = count;
+            g.skip_to = (uint32_t)segments.size() + 1u;
             segments.push_back(g);
+        };
+        /* bounding sphere + steepness data of the triangles [lo, hi); false: the node cannot be skipped */
+        auto node_stats = [&](uint32_t lo_t, uint32_t hi_t, rt::DevSegment *g) -> bool {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t k = lo_t; k < hi_t; ++k)
+                for (int v = 0; v < 3; ++v)
+                    for (int a = 0; a < 3; ++a) {
+                        const double x = (double)desc->triangles[k].vertices[v].position[a];
+                        if (x < lo[a]) lo[a] = x;
+                        if (x > hi[a]) hi[a] = x;
+                    }
+            for (int a = 0; a < 3; ++a) g->c[a] = (float)(0.5 * (lo[a] + hi[a]));
+            double r2 = 0.0;
+            for (uint32_t k = lo_t; k < hi_t; ++k) { /* the sphere must contain every triangle's own bounding sphere */
+                const double dx = (double)tris[k].bcx - g->c[0], dy = (double)tris[k].bcy - g->c[1], dz = (double)tris[k].bcz - g->c[2];
+                const double reach = sqrt(dx * dx + dy * dy + dz * dz) + sqrt((double)tris[k].bq);
+                if (reach * reach > r2) r2 = reach * reach;
+            }
+            const double radius = sqrt(r2);
+            if (!(std::isfinite(radius) && radius <= max_frac * scene_extent && radius >= 1e-3 * scene_extent)) return false;
+            /* (1.05 R)^2 with R already holding the triangles' own 1.05 margins: generous, and rounded up */
+            g->r2_hi = std::nextafter((float)(r2 * 1.0001), std::numeric_limits<float>::infinity());
+            /* one representative per face plane direction: sign canonicalised, merged within 1e-4 per component */
+            bool explicit_ok = true;
+            g->n_normals = 0u;
+            double mean[3] = {0.0, 0.0, 0.0};
+            for (uint32_t k = lo_t; k < hi_t; ++k) {
+                float n[3] = {tris[k].n[0], tris[k].n[1], tris[k].n[2]};
+                if (!(std::isfinite(n[0]) && std::isfinite(n[1]) && std::isfinite(n[2]))) return false;
+                const int lead = fabsf(n[0]) > 1e-3f ? 0 : (fabsf(n[1]) > 1e-3f ? 1 : 2);
+                if (n[lead] < 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                bool known = false;
+                for (uint32_t q = 0; q < g->n_normals && !known; ++q)
+                    known = fabsf(g->normals[q][0] - n[0]) <= 1e-4f && fabsf(g->normals[q][1] - n[1]) <= 1e-4f && fabsf(g->normals[q][2] - n[2]) <= 1e-4f;
+                if (!known && explicit_ok) {
+                    if (g->n_normals == RT_SEGMENT_NORMALS) explicit_ok = false;
+                    else {
+                        g->normals[g->n_normals][0] = n[0]; g->normals[g->n_normals][1] = n[1]; g->normals[g->n_normals][2] = n[2];
+                        g->n_normals += 1u;
+                    }
+                }
+            }
+            if (explicit_ok && g->n_normals != 0u) return true;
+            if (flat_only) return false;
+            /* More than 8 plane directions: a CONE.  Axis a (unit), half-angle theta >= the angle between a and every face normal
+             * or its negative.  For a unit direction d and a unit normal n within theta of +-a:
+             *     |n.d| >= |a.d| cos(theta) - sin(theta),
+             * so |a.d| >= (1.01e-3 + sin theta) / cos theta =: K implies |n.d| >= 1.01e-3 for every triangle below — the
+             * condition the explicit normals test one by one (the 1 % covers the binary32 evaluation of both sides and of the
+             * loop's own n.d).  Stored as K^2 for the test (a.d)^2 >= K^2 (d.d); cones of 60 degrees and more are useless. */
+            for (uint32_t k = lo_t; k < hi_t; ++k) { /* the axis: mean of the normals, each flipped into the first one's half-space */
+                const double s = ((double)tris[k].n[0] * tris[lo_t].n[0] + (double)tris[k].n[1] * tris[lo_t].n[1] + (double)tris[k].n[2] * tris[lo_t].n[2]) < 0.0 ? -1.0 : 1.0;
+                for (int a = 0; a < 3; ++a) mean[a] += s * (double)tris[k].n[a];
+            }
+            const double ml = sqrt(mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+            if (!(ml > 1e-6)) return false;
+            float ax[3];
+            for (int a = 0; a < 3; ++a) ax[a] = (float)(mean[a] / ml);
+            const double al = sqrt((double)ax[0] * ax[0] + (double)ax[1] * ax[1] + (double)ax[2] * ax[2]); /* of the ROUNDED axis: what the kernel uses */
+            double cos_min = 1.0;
+            for (uint32_t k = lo_t; k < hi_t; ++k) {
+                const double nl = sqrt((double)tris[k].n[0] * tris[k].n[0] + (double)tris[k].n[1] * tris[k].n[1] + (double)tris[k].n[2] * tris[k].n[2]);
+                const double c = fabs(((double)tris[k].n[0] * ax[0] + (double)tris[k].n[1] * ax[1] + (double)tris[k].n[2] * ax[2]) / (nl * al));
+                if (!(c <= 1.0)) { if (c > 1.0 && c < 1.0 + 1e-9) continue; return false; }
+                if (c < cos_min) cos_min = c;
+            }
+            const double theta = acos(cos_min) + 1e-5; /* slack for everything rounded on the way */
+            if (!(theta < 1.0471975511965976)) return false; /* 60 degrees */
+            const double K = (1.01e-3 + sin(theta)) / cos(theta) * 1.0001;
+            if (!(K < 1.0)) return false;
+            g->n_normals = RT_SEGMENT_CONE;
+            /* the kernel compares (a.d)^2 with K^2 (d.d) where a is the rounded axis of length al: fold al^2 in, round up */
+            g->normals[0][0] = ax[0]; g->normals[0][1] = ax[1]; g->normals[0][2] = ax[2];
+            g->normals[0][3] = std::nextafter((float)(K * K * al * al * 1.0001), std::numeric_limits<float>::infinity());
+            return true;
+        };
+        /* pre-order emission of the tree over the leaves [l0, l1) of the object run [run_lo, run_hi) */
+        struct Emit {
+            static void go(uint32_t l0, uint32_t l1, uint32_t run_lo, uint32_t run_hi, std::vector<rt::DevSegment> &out,
+                           const std::function<bool(uint32_t, uint32_t, rt::DevSegment *)> &stats,
+                           const std::function<void(uint32_t, uint32_t)> &plain) {
+                const uint32_t t0 = run_lo + l0 * RT_LEAF_TRIANGLES;
+                const uint32_t t1 = std::min<uint64_t>(run_hi, (uint64_t)run_lo + (uint64_t)l1 * RT_LEAF_TRIANGLES);
+                rt::DevSegment g;
+                memset(&g, 0, sizeof g);
+                const bool ok = stats(t0, t1, &g);
+                if (l1 - l0 == 1u) {
+                    if (!ok) { plain(t0, t1 - t0); return; }
+                    g.first = t0;
+                    g.count = t1 - t0;
+                    g.skip_to = (uint32_t)out.size() + 1u;
+                    out.push_back(g);
+                    return;
+                }
+                size_t at = (size_t)-1;
+                if (ok) { /* an inner node: count 0, skip_to patched once its subtree is out */
+                    g.first = t0;
+                    g.count = 0u;
+                    at = out.size();
+                    out.push_back(g);
+                }
+                uint32_t child = 1u; /* leaves per child: the largest power of 16 below the span */
+                while ((uint64_t)child * 16u < (uint64_t)(l1 - l0)) child *= 16u;
+                for (uint32_t c0 = l0; c0 < l1; c0 += child) go(c0, std::min(l1, c0 + child), run_lo, run_hi, out, stats, plain);
+                if (at != (size_t)-1) out[at].skip_to = (uint32_t)out.size();
+            }
         };
         for (uint32_t i = 0; i < desc->n_triangles;) {
             uint32_t j = i;
             while (j < desc->n_triangles && desc->triangles[j].object_index == desc->triangles[i].object_index) ++j;
             bool ok = !clusters_off && j - i >= 8u;
             for (uint32_t k = i; ok && k < j; ++k) ok = std::isfinite(tris[k].bq); /* every triangle qualifies for its own rejection */
-            rt::DevSegment g;
-            memset(&g, 0, sizeof g);
-            if (ok) {
-                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                for (uint32_t k = i; k < j; ++k)
-                    for (int v = 0; v < 3; ++v)
-                        for (int a = 0; a < 3; ++a) {
-                            const double x = (double)desc->triangles[k].vertices[v].position[a];
-                            if (x < lo[a]) lo[a] = x;
-                            if (x > hi[a]) hi[a] = x;
-                        }
-                for (int a = 0; a < 3; ++a) g.c[a] = (float)(0.5 * (lo[a] + hi[a]));
-                double r2 = 0.0;
-                for (uint32_t k = i; k < j; ++k) { /* the sphere must contain every triangle's own bounding sphere */
-                    const double dx = (double)tris[k].bcx - g.c[0], dy = (double)tris[k].bcy - g.c[1], dz = (double)tris[k].bcz - g.c[2];
-                    const double reach = sqrt(dx * dx + dy * dy + dz * dz) + sqrt((double)tris[k].bq);
-                    if (reach * reach > r2) r2 = reach * reach;
-                }
-                const double radius = sqrt(r2);
-                ok = std::isfinite(radius) && radius <= max_frac * scene_extent && radius >= 1e-3 * scene_extent;
-                /* one representative per face plane direction: sign canonicalised, merged within 1e-4 per component */
-                for (uint32_t k = i; ok && k < j; ++k) {
-                    float n[3] = {tris[k].n[0], tris[k].n[1], tris[k].n[2]};
-                    ok = std::isfinite(n[0]) && std::isfinite(n[1]) && std::isfinite(n[2]);
-                    const int lead = fabsf(n[0]) > 1e-3f ? 0 : (fabsf(n[1]) > 1e-3f ? 1 : 2);
-                    if (n[lead] < 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-                    bool known = false;
-                    for (uint32_t q = 0; q < g.n_normals && !known; ++q)
-                        known = fabsf(g.normals[q][0] - n[0]) <= 1e-4f && fabsf(g.normals[q][1] - n[1]) <= 1e-4f && fabsf(g.normals[q][2] - n[2]) <= 1e-4f;
-                    if (!known && ok) {
-                        if (g.n_normals == RT_SEGMENT_NORMALS) { ok = false; break; }
-                        g.normals[g.n_normals][0] = n[0]; g.normals[g.n_normals][1] = n[1]; g.normals[g.n_normals][2] = n[2];
-                        g.n_normals += 1u;
-                    }
-                }
-                /* (1.05 R)^2 with R already holding the triangles' own 1.05 margins: generous, and rounded up */
-                g.r2_hi = std::nextafter((float)(r2 * 1.0001), std::numeric_limits<float>::infinity());
-            }
-            if (ok && g.n_normals != 0u) {
-                g.first = i;
-                g.count = j - i;
-                segments.push_back(g);
-            } else {
+            if (!ok) {
                 push_plain(i, j - i);
+            } else if (flat_only || j - i <= 64u) {
+                /* a small object is ONE leaf (the reference scene's dodecahedron: 36 triangles, 6 plane directions — one test per
+                 * cast decides it; as a tree of three leaves it cost the bench frame 3 %) */
+                rt::DevSegment g;
+                memset(&g, 0, sizeof g);
+                if (node_stats(i, j, &g)) { g.first = i; g.count = j - i; g.skip_to = (uint32_t)segments.size() + 1u; segments.push_back(g); }
+                else if (flat_only) push_plain(i, j - i);
+                else Emit::go(0u, (j - i + RT_LEAF_TRIANGLES - 1u) / RT_LEAF_TRIANGLES, i, j, segments, node_stats, push_plain);
+            } else {
+                const uint32_t n_leaves = (j - i + RT_LEAF_TRIANGLES - 1u) / RT_LEAF_TRIANGLES;
+                Emit::go(0u, n_leaves, i, j, segments, node_stats, push_plain);
             }
             i = j;
         }
@@ -388,8 +472,11 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
      * (WEAK) equal up to the signs of zero components */
     if (getenv("RT_AMD_NO_PLANE_SHARING") == nullptr && desc->n_materials <= RT_TRI_OBJ_MASK) { /* A/B switch; results are the same either way */
         const bool weak_ok = getenv("RT_AMD_NO_WEAK_PLANE_SHARING") == nullptr;
-        for (const rt::DevSegment &g : segments)
-            for (uint32_t i = g.first + 1u; i < g.first + g.count; ++i) {
+        /* any two consecutive triangles of one object: a call of the loop covers consecutive records and treats its first triangle
+         * as a leader whatever its flag says, so a pair may straddle leaves */
+        for (uint32_t i = 1u; i < desc->n_triangles; ++i) {
+            if (desc->triangles[i].object_index != desc->triangles[i - 1u].object_index) continue;
+            {
                 const float a[4] = {tris[i - 1u].n[0], tris[i - 1u].n[1], tris[i - 1u].n[2], tris[i - 1u].d};
                 const float b[4] = {tris[i].n[0], tris[i].n[1], tris[i].n[2], tris[i].d};
                 bool exact = true, weak = true;
@@ -401,6 +488,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
                 if (exact) tris[i].obj |= RT_TRI_FOLLOWS;
                 else if (weak && weak_ok) tris[i].obj |= RT_TRI_FOLLOWS | RT_TRI_FOLLOWS_WEAK;
             }
+        }
     }
     std::vector<rt::DevSphere> spheres(desc->n_spheres);
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {

@@ -209,13 +209,19 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
 __device__ __forceinline__ bool cluster_skippable(const DevSegment &g, const Ray &ray, const CastMasks &m) {
     const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - ray.o;
     const V3 cr = cross(disp, ray.d);
-    const bool miss = dot(cr, cr) > g.r2_hi * dot(ray.d, ray.d);
+    const float dd = dot(ray.d, ray.d);
+    const bool miss = dot(cr, cr) > g.r2_hi * dd;
     if (__builtin_amdgcn_ballot_w64(miss) != (__builtin_amdgcn_ballot_w64(true) & m.filter_ok) ||
         (__builtin_amdgcn_ballot_w64(true) & ~m.filter_ok) != 0ull)
         return false; /* some lane may hit the sphere, or starts far outside the scene */
     bool steep = true;
-    for (uint32_t k = 0; k < g.n_normals; ++k)
-        steep = steep && rtdm::f_abs(dot(v3(g.normals[k][0], g.normals[k][1], g.normals[k][2]), ray.d)) >= 1.0e-3f;
+    if (g.n_normals == RT_SEGMENT_CONE) { /* a normal cone instead of a list (rt_device_scene.h) */
+        const float ad = dot(v3(g.normals[0][0], g.normals[0][1], g.normals[0][2]), ray.d);
+        steep = ad * ad >= g.normals[0][3] * dd;
+    } else {
+        for (uint32_t k = 0; k < g.n_normals; ++k)
+            steep = steep && rtdm::f_abs(dot(v3(g.normals[k][0], g.normals[k][1], g.normals[k][2]), ray.d)) >= 1.0e-3f;
+    }
     return __builtin_amdgcn_ballot_w64(steep) == __builtin_amdgcn_ballot_w64(true);
 }
 
@@ -282,18 +288,23 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
     best.t = rtdm::quiet_nan();
     best.prim = -1;
     best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
-    /* The triangles in index order, segment by segment; a clustered segment that no lane can hit is not visited.
-     * Neighbouring segments that are visited go through the loop in one call (its set-up and first fetches are paid once). */
+    /* The triangles in index order: a walk over the node array (rt_device_scene.h) — a node that no lane can hit is left
+     * out together with everything below it, an inner node that somebody may hit is descended into, and the triangles of
+     * neighbouring leaves that are visited go through the loop in one call (its set-up and first fetches are paid once). */
     uint32_t run_first = 0u, run_count = 0u;
-    for (uint32_t k = 0; k < sc.n_segments; ++k) {
+    const uint32_t n_nodes = sc.n_segments;
+    for (uint32_t k = 0; k < n_nodes;) {
         const DevSegment &g = sc.segments[k];
         if (g.n_normals != 0u && cluster_skippable(g, ray, m)) {
             if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
             run_count = 0u;
+            k = g.skip_to;
             continue;
         }
+        k += 1u;
+        if (g.count == 0u) continue; /* an inner node somebody may hit: on to its children */
         if (run_count == 0u) run_first = g.first;
-        run_count += g.count; /* segments are contiguous in triangle order */
+        run_count += g.count; /* leaves are contiguous in triangle order unless something was skipped in between (then the run was closed) */
     }
     if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
     return cast_finish(sc, ray, best.t, best.prim, &best);

@@ -65,21 +65,30 @@ struct alignas(16) DevTriAttr {
 };
 static_assert(sizeof(DevTriAttr) == 64, "DevTriAttr must be 64 bytes");
 
-/* A run of consecutive triangles.  The intersection loop visits the segments in order (so the reference's sequential
- * nearest-hit rule is kept).  A segment with n_normals != 0 is a CLUSTER — a run of one object's triangles with a
- * bounding sphere — and is skipped when, for every lane of the wave, the ray's line misses the sphere inflated by 5 %
- * (folded into r2_hi), the origin is in the scene's neighbourhood, and |n . d| >= 1e-3 for each representative face
- * normal (one per face, antipodal ones merged): then every triangle in it computes a finite t and a finite plane point
- * that lies outside the triangle's own bounding circle by the margin of the per-triangle rejection above, i.e. the
- * reference would reject it on a negative signed area.  rt_scene_create only clusters runs all of whose triangles
- * qualify for that per-triangle rejection. */
+/* The triangles as a pre-order array of NODES.  A LEAF (count != 0) is a run of consecutive triangles; an INNER node
+ * (count == 0) covers the leaves that follow it up to skip_to.  The intersection loop walks the array in order (so the
+ * reference's sequential nearest-hit rule is kept: triangles are still visited in index order, only ones that nobody can hit
+ * are left out): a node with n_normals != 0 is SKIPPED — the walk continues at skip_to — when, for every lane of the wave,
+ * the ray's line misses the node's bounding sphere inflated by 5 % (folded into r2_hi), the origin is in the scene's
+ * neighbourhood, and the ray is not (nearly) parallel to any face plane below: |n . d| >= 1e-3 for each representative
+ * face normal (n_normals = 1..8: one per plane direction, antipodal ones merged), or, for a node with more plane directions
+ * than that, (a . d)^2 >= K^2 (d . d) for its normal CONE (n_normals = RT_SEGMENT_CONE: axis a in normals[0][0..2], K^2 in
+ * normals[0][3]; rt_api.hip derives K from the cone's half-angle so that the condition implies the per-normal one).  Then
+ * every triangle below computes a finite t and a finite plane point that lies outside the triangle's own bounding circle by
+ * the margin of the per-triangle rejection above, i.e. the reference would reject it on a negative signed area.
+ * rt_scene_create only builds such nodes over triangles all of which qualify for that per-triangle rejection; an inner node
+ * is only emitted if it can be skipped at all; a leaf with n_normals == 0 is always visited. */
 #define RT_SEGMENT_NORMALS 8
+#define RT_SEGMENT_CONE 0xffffffffu
+#ifndef RT_LEAF_TRIANGLES
+#define RT_LEAF_TRIANGLES 16u
+#endif
 struct alignas(16) DevSegment {
-    uint32_t first, count;
-    uint32_t n_normals; /* 0: plain run, always visited */
-    float r2_hi;        /* (1.05 R)^2, rounded up */
+    uint32_t first, count; /* count == 0: inner node */
+    uint32_t n_normals;    /* 0: plain leaf, always visited */
+    float r2_hi;           /* (1.05 R)^2, rounded up */
     float c[3];
-    float pad;
+    uint32_t skip_to;      /* index of the first node after this one's subtree (leaf: its own index + 1) */
     float normals[RT_SEGMENT_NORMALS][4];
 };
 static_assert(sizeof(DevSegment) == 160, "DevSegment layout");

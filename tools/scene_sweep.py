@@ -32,6 +32,7 @@ ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen per size)")
 ap.add_argument("--no-parity", action="store_true")
 ap.add_argument("--out", default=None)
+ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
 import numpy as np
@@ -40,6 +41,12 @@ import torch
 import homework_18_graphics_raytracer_amd as rt
 from homework_18_graphics_raytracer_amd import _capi
 
+if a.lib:
+    import ctypes as C
+
+    _capi._amd = None
+    _orig = _capi._load
+    _capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / f"librt_amd_{a.lib}.so")) if name == "librt_amd.so" else _orig(name)
 lib = _capi.amd_lib()
 cam = rt.reference_camera()
 lines = []
