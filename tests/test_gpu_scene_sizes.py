@@ -1,0 +1,85 @@
+"""Scenes beyond the reference's 64 triangles, through the scene FILE: the literal scene around a tessellated
+dodecahedron (tools/make_tessellated_obj.py -> load_obj -> rt_world_save_scene -> rt_world_load_scene).  Objects of more than
+64 triangles are visited through the cluster TREE of rt_device_scene.h (16-triangle leaves, inner nodes with skip pointers,
+normal cones where a node has more than 8 plane directions); flat tessellations also share planes between coplanar pieces.
+Every render path and the stochastic pass must stay bit-identical to the oracle's brute-force loop."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import homework_18_graphics_raytracer_amd as rt
+from homework_18_graphics_raytracer_amd import _capi
+import _oracle
+import _scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _scene(tmp_path, level, spherize):
+    obj = tmp_path / f"d{level}{'s' if spherize else 'f'}.obj"
+    cmd = [sys.executable, str(ROOT / "tools" / "make_tessellated_obj.py"), rt.DEFAULT_OBJ, str(obj), "--levels", str(level)]
+    subprocess.run(cmd + (["--spherize"] if spherize else []), check=True, capture_output=True)
+    path = tmp_path / "scene.rtscene"
+    rt.reference_world(str(obj)).save_scene(path, rt.reference_camera())
+    return rt.World.load_scene(path)
+
+
+def _same(a, b):
+    return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+@pytest.mark.parametrize("level,spherize", [(1, True), (2, True), (3, True), (2, False), (3, False)])
+def test_whitted_on_tessellated_scenes(tmp_path, level, spherize):
+    world, cam = _scene(tmp_path, level, spherize)
+    desc = world.desc()
+    assert desc.n_triangles == 36 * 4 ** level + 28
+    scene = rt.Scene(world)
+    lib = _capi.amd_lib()
+    views = [(cam, rt.Frame.full(128, 96, 5)),
+             # an axis-aligned camera looking at the solid from a grid point: rays exactly parallel to planes of the flat faces
+             (_scenes.axis_camera((0.7, 1.0, 3.0)), rt.Frame.full(64, 64, 4))]
+    for camera, frame in views:
+        want, wcasts = _oracle.render_whitted(desc, camera, frame)
+        for variant in (18, 2):
+            _capi.check(lib.rt_set_variant(variant))
+            try:
+                got, casts = rt.render_whitted_numpy(scene, camera, frame)
+            finally:
+                _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
+            assert _same(got, want) and casts == wcasts, (variant, frame.width)
+
+
+@pytest.mark.parametrize("level,spherize", [(2, True), (2, False)])
+def test_stochastic_pass_on_tessellated_scenes(tmp_path, level, spherize):
+    import torch
+
+    world, cam = _scene(tmp_path, level, spherize)
+    desc = world.desc()
+    scene = rt.Scene(world)
+    frame = rt.Frame.full(64, 48, 5)
+    rng = rt.Rng(frame)
+    samples = torch.empty((2, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    valid = torch.empty((2, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, cam, frame, rng, 2, samples=samples, valid=valid, ray_count=cnt)
+    torch.cuda.synchronize()
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(desc, cam, frame, st, 2)
+    assert _same(samples.cpu().numpy(), ws) and np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
+    assert np.array_equal(rng.download(), st)
+
+
+def test_rt_render_renders_a_scene_file(tmp_path):
+    """`rt_render --save-scene` then `--scene`: the same PNG as the literal scene (the file carries the camera)."""
+    common = ["--width", "160", "--height", "120", "--depth", "5"]
+    a, b, f = tmp_path / "a.png", tmp_path / "b.png", tmp_path / "ref.rtscene"
+    exe = str(_capi.PKG_DIR / "rt_render")
+    done = subprocess.run([exe] + common + ["--obj", rt.DEFAULT_OBJ, "--out", str(a), "--save-scene", str(f)], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    done = subprocess.run([exe] + common + ["--out", str(b), "--scene", str(f)], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    assert a.read_bytes() == b.read_bytes()
