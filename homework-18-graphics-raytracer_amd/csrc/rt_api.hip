@@ -327,6 +327,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     {
         const bool clusters_off = filter_off || getenv("RT_AMD_NO_CLUSTERS") != nullptr; /* A/B switch; results are the same either way */
         const bool flat_only = getenv("RT_AMD_NO_HIERARCHY") != nullptr; /* A/B: one cluster per object run, explicit normals only (round 1) */
+        uint32_t single_leaf_max = 64u; /* A/B: objects up to this many triangles stay one leaf */
+        if (const char *v = getenv("RT_AMD_SINGLE_LEAF_MAX")) { if (*v) single_leaf_max = (uint32_t)atoi(v); }
         auto push_plain = [&](uint32_t first, uint32_t count) {
             if (!segments.empty() && segments.back().n_normals == 0u && segments.back().count != 0u &&
                 segments.back().first + segments.back().count == first) {
@@ -453,7 +455,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
             for (uint32_t k = i; ok && k < j; ++k) ok = std::isfinite(tris[k].bq); /* every triangle qualifies for its own rejection */
             if (!ok) {
                 push_plain(i, j - i);
-            } else if (flat_only || j - i <= 64u) {
+            } else if (flat_only || j - i <= single_leaf_max) {
                 /* a small object is ONE leaf (the reference scene's dodecahedron: 36 triangles, 6 plane directions — one test per
                  * cast decides it; as a tree of three leaves it cost the bench frame 3 %) */
                 rt::DevSegment g;

@@ -89,12 +89,11 @@ namespace rt {
 #ifndef PA_SLEEP
 #define PA_SLEEP 16
 #endif
-#ifndef PA_SHADE_DL
-#define PA_SHADE_DL 0 /* 1: a SHADE item carries the light as its producer evaluated it (96 B instead of 80 B) so that the consumer
-                       * need not evaluate it again (for a spot light an acos and a powf in binary64).  Measured SLOWER, 1.51 ms per
-                       * frame against 1.28 ms (profiles/README.md, round 2): the sixth field costs more than the arithmetic saves */
-#endif
-#define PA_SHADE_U4 (PA_SHADE_DL ? 6u : 5u) /* uint4s per SHADE item */
+/* A SHADE item is 80 bytes and its consumer evaluates its light again (for a spot light an acos and a powf in binary64).  Twice
+ * the light was made to travel with the item instead — as direction + colour in a sixth field (96 B), and as the colour in place
+ * of the diffuse colour, which the consumer then re-derived from the material and uv (80 B) — and twice the frame got SLOWER,
+ * 1.51 and 1.31 ms against 1.28 (profiles/README.md, round 2): the evaluation runs under the item loads' latency. */
+#define PA_SHADE_U4 5u /* uint4s per SHADE item */
 #define PA_SPIN_LIMIT (1u << 22)
 
 enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u };
@@ -358,14 +357,6 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         } else { /* PA_T_SHADE */
             if (active) {
                 const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
-#if PA_SHADE_DL
-                /* before the cast only what the shadow ray needs: the shaded point, the primitive to exclude and the light's
-                 * direction as the producer evaluated it (approximate_into_directional of light_i at spos) */
-                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)];
-                id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
-                spos = v3(puf(b.x), puf(b.y), puf(b.z));
-                dl.direction = v3(puf(a.w), puf(b.w), puf(reinterpret_cast<const uint32_t *>(t + PA_F(2u))[3]));
-#else
                 const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
                 id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
                 spos = v3(puf(b.x), puf(b.y), puf(b.z)); sum.x = puf(b.w);
@@ -373,7 +364,6 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
                 sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z));
                 do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl); /* always true for a queued item */
-#endif
                 req.o = spos;
                 req.d = -dl.direction;
                 req.mode = FACE_BACK;
@@ -474,20 +464,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             const uint32_t k_shade = lds_append(&S.s.alloc, want_shade);
             if (want_shade) {
                 uint4 *t = shade_q + pa_entry(k_shade & ring_mask, PA_SHADE_U4);
-#if PA_SHADE_DL
-                t[PA_F(0u)] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), pfu(dl.direction.x));
-                t[PA_F(1u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(dl.direction.y));
-                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(dl.direction.z));
-                t[PA_F(3u)] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
-                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), pfu(0.0f));
-                t[PA_F(5u)] = make_uint4(pfu(dl.color.x), pfu(dl.color.y), pfu(dl.color.z), pfu(0.0f));
-#else
                 t[PA_F(0u)] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), 0u);
                 t[PA_F(1u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(0.0f));
                 t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(0.0f));
                 t[PA_F(3u)] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
                 t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
-#endif
             }
             pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
         } else if (type == PA_T_REFR) {
@@ -550,19 +531,6 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         } else {
             /* ---- one light of get_shade (main.rs:435-461) ---- */
             bool again = false;
-#if PA_SHADE_DL
-#ifdef PA_SHADE_BARRIER
-            asm volatile("" ::: "memory"); /* the rest of the item is read here, not before the cast */
-#endif
-            if (active) {
-                const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
-                const uint4 c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)], f = t[PA_F(5u)];
-                adj_n = v3(puf(c.x), puf(c.y), puf(c.z));
-                in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.x = puf(d.w);
-                sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z)); sum.y = puf(e.w);
-                dl.color = v3(puf(f.x), puf(f.y), puf(f.z)); sum.z = puf(f.w);
-            }
-#endif
             if (active) {
                 const rt_material &rm = sc.materials[obj];
                 if (do_cast) {
@@ -613,20 +581,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             const uint32_t k_again = lds_append(&S.s.alloc, again);
             if (again) {
                 uint4 *t = shade_q + pa_entry(k_again & ring_mask, PA_SHADE_U4);
-#if PA_SHADE_DL
-                t[PA_F(0u)] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), pfu(dl.direction.x));
-                t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(dl.direction.y));
-                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(dl.direction.z));
-                t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.x));
-                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), pfu(sum.y));
-                t[PA_F(5u)] = make_uint4(pfu(dl.color.x), pfu(dl.color.y), pfu(dl.color.z), pfu(sum.z));
-#else
                 t[PA_F(0u)] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), 0u);
                 t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
                 t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
                 t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
                 t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
-#endif
             }
             pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
         }
