@@ -94,12 +94,18 @@ namespace rt {
  * of the diffuse colour, which the consumer then re-derived from the material and uv (80 B) — and twice the frame got SLOWER,
  * 1.51 and 1.31 ms against 1.28 (profiles/README.md, round 2): the evaluation runs under the item loads' latency. */
 #define PA_SHADE_U4 5u /* uint4s per SHADE item */
+#ifndef PA_LDS_PAGES
+#define PA_LDS_PAGES 8u /* pages of SHADE items held in LDS (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
+#endif
 #define PA_SPIN_LIMIT (1u << 22)
 
-enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u };
+enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u, PA_T_SHADE_LDS = 5u };
 
 struct PaShared {
     PaQueue n, f, s;          /* NODE (positions are node ids), REFR ring, SHADE ring */
+    PaQueue l;                /* the SHADE items held in LDS */
+    uint32_t l_released;      /* pages of `l` whose items have been read: their slots may be written again */
+    uint32_t ready_l[PA_LDS_PAGES];
     uint32_t root_alloc;      /* root nodes, handed out from the top of the arena downwards */
     uint32_t tiles_exhausted; /* the frame-wide counter ran out, or this arena has no room for another tile */
     uint32_t tile_list_count;
@@ -108,6 +114,16 @@ struct PaShared {
     uint32_t done;            /* all waves idle at once: the queues are final */
     uint32_t abort;
 };
+
+/* the five fields of a SHADE item (t: field 0 of its entry, in the arena's ring or in LDS) */
+template <class P>
+__device__ __forceinline__ void pa_store_shade(P *t, uint32_t id, uint32_t prim, uint32_t word, V3 spos, V3 adj_n, V3 in_dir, V3 sdiffuse, V3 sum) {
+    t[PA_F(0u)] = make_uint4(id, prim, word, 0u);
+    t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
+    t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
+    t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
+    t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+}
 
 #ifdef PA_STATS
 /* diagnostic build: wave time by phase (s_memtime ticks, summed over all waves) and chunk / lane counts by item type:
@@ -122,6 +138,7 @@ __device__ unsigned long long pa_phase_stats[32];
 __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
+    __shared__ uint4 lds_shade[PA_LDS_PAGES * PA_SHADE_U4 * 64u];
     const KernelFrame &fr = *pp.frame;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_slots = fr.cols * fr.rows;
@@ -149,6 +166,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         S.n.alloc = S.n.taken = 0u;
         S.f.alloc = S.f.taken = 0u;
         S.s.alloc = S.s.taken = 0u;
+        S.l.alloc = S.l.taken = 0u;
+        S.l_released = 0u;
+        for (uint32_t k = 0; k < PA_LDS_PAGES; ++k) S.ready_l[k] = 0u;
         S.root_alloc = 0u;
         S.tiles_exhausted = 0u;
         S.tile_list_count = 0u;
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             for (int pass = 0; pass < 2 && type == PA_T_NONE; ++pass) {
                 /* a fresh tile: before SHADE work while little of it is queued (pass 0), else after the full pages (pass 1) */
                 if (!tried_tile && lds_load(&S.tiles_exhausted) == 0u) {
-                    const uint32_t shade_pages = (lds_load(&S.s.alloc) >> 6) - lds_load(&S.s.taken);
+                    const uint32_t shade_pages = ((lds_load(&S.s.alloc) >> 6) - lds_load(&S.s.taken)) + ((lds_load(&S.l.alloc) >> 6) - lds_load(&S.l.taken));
                     if (pass == 1 || (int32_t)shade_pages < (int32_t)PA_SHADE_PAGES) {
                         tried_tile = true;
                         const uint32_t used = lds_load(&S.n.alloc) + lds_load(&S.root_alloc);
@@ -215,8 +235,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     }
                 }
                 if (type == PA_T_NONE && pass == 0) {
-                    count = pa_claim(&S.s, ready_s, ring_page_mask, 0u, &start);
-                    if (count != 0u) type = PA_T_SHADE;
+                    count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, 0u, &start);
+                    if (count != 0u) type = PA_T_SHADE_LDS;
+                    if (type == PA_T_NONE) {
+                        count = pa_claim(&S.s, ready_s, ring_page_mask, 0u, &start);
+                        if (count != 0u) type = PA_T_SHADE;
+                    }
                 }
             }
             /* Partly filled pages: waiting for them to fill would hold up the chains behind their items, but a page taken
@@ -228,6 +252,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 if (count != 0u) { type = PA_T_NODE; break; }
                 count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
                 if (count != 0u) { type = PA_T_REFR; break; }
+                count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, min_partial, &start);
+                if (count != 0u) { type = PA_T_SHADE_LDS; break; }
                 count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
                 if (count != 0u) { type = PA_T_SHADE; break; }
                 if (last) {
@@ -257,6 +283,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         type = (uint32_t)__builtin_amdgcn_readfirstlane((int)type);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
+        const bool shade_in_lds = type == PA_T_SHADE_LDS;
+        if (shade_in_lds) type = PA_T_SHADE;
 #ifdef PA_STATS
         const unsigned long long ph_t1 = PA_TICK();
         if (type == PA_T_NONE) ph[24] += ph_t1 - ph_t0;
@@ -355,9 +383,27 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 retry = (int32_t)c.w;
             }
         } else { /* PA_T_SHADE */
-            if (active) {
+            uint4 a, b, c, d, e;
+            a = b = c = d = e = make_uint4(0u, 0u, 0u, 0u);
+            if (shade_in_lds) {
+                if (active) {
+                    const uint4 *t = lds_shade + pa_entry((start + lane) & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4);
+                    a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
+                }
+                /* the page's slot may be written again once its items are in registers.  Pages are released in the order they
+                 * were claimed: a wave may wait here for the one before it, which is between its claim and this point too and
+                 * has nothing but its own LDS reads to wait for */
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0u) {
+                    const uint32_t page = start >> 6;
+                    while (lds_load(&S.l_released) != page) __builtin_amdgcn_s_sleep(1);
+                    __hip_atomic_store(&S.l_released, page + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (active) {
                 const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
-                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
+                a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
+            }
+            if (active) {
                 id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
                 spos = v3(puf(b.x), puf(b.y), puf(b.z)); sum.x = puf(b.w);
                 adj_n = v3(puf(c.x), puf(c.y), puf(c.z)); sum.y = puf(c.w);
@@ -461,16 +507,20 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 light_i = 0u;
                 want_shade = next_shadow_ray(sc, &light_i, nh.pos, adj_n, &dl); /* no light needs a cast: get_shade = black */
             }
-            const uint32_t k_shade = lds_append(&S.s.alloc, want_shade);
-            if (want_shade) {
-                uint4 *t = shade_q + pa_entry(k_shade & ring_mask, PA_SHADE_U4);
-                t[PA_F(0u)] = make_uint4(id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), 0u);
-                t[PA_F(1u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(0.0f));
-                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(0.0f));
-                t[PA_F(3u)] = make_uint4(pfu(req.d.x), pfu(req.d.y), pfu(req.d.z), pfu(0.0f));
-                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+            {
+                const uint32_t word = nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u);
+                const V3 zero = v3(0.0f, 0.0f, 0.0f);
+                bool in_lds;
+                uint32_t k_shade = pa_try_append(&S.l, &S.l_released, PA_LDS_PAGES * 64u, want_shade, &in_lds);
+                if (in_lds) {
+                    if (want_shade) pa_store_shade(lds_shade + pa_entry(k_shade & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, nh.prim, word, nh.pos, adj_n, req.d, sdiffuse, zero);
+                    pa_publish(S.ready_l, PA_LDS_PAGES - 1u, want_shade, k_shade, &S.gen);
+                } else {
+                    k_shade = lds_append(&S.s.alloc, want_shade);
+                    if (want_shade) pa_store_shade(shade_q + pa_entry(k_shade & ring_mask, PA_SHADE_U4), id, nh.prim, word, nh.pos, adj_n, req.d, sdiffuse, zero);
+                    pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
+                }
             }
-            pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
         } else if (type == PA_T_REFR) {
             /* ---- one step of get_refract (main.rs:371-403) ---- */
             bool requeue = false, escape = false;
@@ -578,16 +628,19 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     rec[2] = acc.z;
                 }
             }
-            const uint32_t k_again = lds_append(&S.s.alloc, again);
-            if (again) {
-                uint4 *t = shade_q + pa_entry(k_again & ring_mask, PA_SHADE_U4);
-                t[PA_F(0u)] = make_uint4(id, prim, obj | (light_i << 16) | (sflags << 31), 0u);
-                t[PA_F(1u)] = make_uint4(pfu(spos.x), pfu(spos.y), pfu(spos.z), pfu(sum.x));
-                t[PA_F(2u)] = make_uint4(pfu(adj_n.x), pfu(adj_n.y), pfu(adj_n.z), pfu(sum.y));
-                t[PA_F(3u)] = make_uint4(pfu(in_dir.x), pfu(in_dir.y), pfu(in_dir.z), pfu(sum.z));
-                t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
+            {
+                const uint32_t word = obj | (light_i << 16) | (sflags << 31);
+                bool in_lds;
+                uint32_t k_again = pa_try_append(&S.l, &S.l_released, PA_LDS_PAGES * 64u, again, &in_lds);
+                if (in_lds) {
+                    if (again) pa_store_shade(lds_shade + pa_entry(k_again & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
+                    pa_publish(S.ready_l, PA_LDS_PAGES - 1u, again, k_again, &S.gen);
+                } else {
+                    k_again = lds_append(&S.s.alloc, again);
+                    if (again) pa_store_shade(shade_q + pa_entry(k_again & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
+                    pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
+                }
             }
-            pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
         }
 #ifdef PA_STATS
         {

@@ -91,6 +91,27 @@ __device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32
     return 0u;
 }
 
+/* all lanes.  lds_append for a queue of bounded capacity (`capacity` positions, a multiple of 64; `released` counts the pages
+ * whose slots may be written again): *ok is false — for the whole wave — when the items do not fit right now. */
+__device__ __forceinline__ uint32_t pa_try_append(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    *ok = true;
+    if (mask == 0ull) return 0u;
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const int leader = (int)__builtin_ctzll(mask);
+    uint32_t base = 0xffffffffu;
+    if ((int)(threadIdx.x & 63u) == leader) {
+        for (int tries = 0; tries < 4; ++tries) {
+            const uint32_t a = lds_load(&q->alloc);
+            if (a + n - (lds_load(released) << 6) > capacity) break; /* full */
+            if (atomicCAS(&q->alloc, a, a + n) == a) { base = a; break; }
+        }
+    }
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (base == 0xffffffffu) { *ok = false; return 0u; }
+    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 /* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
 __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
