@@ -71,7 +71,7 @@ namespace rt {
 #define PA_MIN_WAVES 6
 #endif
 #ifndef PA_SHADE_PAGES
-#define PA_SHADE_PAGES 8u /* a wave starts a fresh tile rather than a SHADE page while fewer SHADE pages than this are queued */
+#define PA_SHADE_PAGES 4u /* a wave starts a fresh tile rather than a SHADE page while fewer SHADE pages than this are queued */
 #endif
 #ifndef PA_MIN_PARTIAL
 #define PA_MIN_PARTIAL 1u /* a partly filled page is taken (sealed) as soon as a wave has nothing fuller to do, whatever it holds: measured
@@ -95,17 +95,30 @@ namespace rt {
  * 1.51 and 1.31 ms against 1.28 (profiles/README.md, round 2): the evaluation runs under the item loads' latency. */
 #define PA_SHADE_U4 5u /* uint4s per SHADE item */
 #ifndef PA_LDS_PAGES
-#define PA_LDS_PAGES 8u /* pages of SHADE items held in LDS (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
+#define PA_LDS_PAGES 4u /* pages of SHADE items held in LDS (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
 #endif
+#ifndef PA_LDS_F_PAGES
+#define PA_LDS_F_PAGES 4u /* the same for REFR items (3 KB each) */
+#endif
+#ifndef PA_LDS_N_PAGES
+#define PA_LDS_N_PAGES 4u /* and for NODE items (3 KB each: the ray, its word and contribution, the node id) */
+#endif
+#define PA_IN_LDS 8u /* type bit: the claimed page is one of an LDS queue */
 #define PA_SPIN_LIMIT (1u << 22)
 
-enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u, PA_T_SHADE_LDS = 5u };
+enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u, PA_T_SHADE = 4u };
 
 struct PaShared {
     PaQueue n, f, s;          /* NODE (positions are node ids), REFR ring, SHADE ring */
     PaQueue l;                /* the SHADE items held in LDS */
     uint32_t l_released;      /* pages of `l` whose items have been read: their slots may be written again */
     uint32_t ready_l[PA_LDS_PAGES];
+    PaQueue lf;               /* the REFR items held in LDS */
+    uint32_t lf_released;
+    uint32_t ready_lf[PA_LDS_F_PAGES];
+    PaQueue ln;               /* the NODE items held in LDS: their nodes' ids come from the top of the arena, like the roots' */
+    uint32_t ln_released;
+    uint32_t ready_ln[PA_LDS_N_PAGES];
     uint32_t root_alloc;      /* root nodes, handed out from the top of the arena downwards */
     uint32_t tiles_exhausted; /* the frame-wide counter ran out, or this arena has no room for another tile */
     uint32_t tile_list_count;
@@ -125,6 +138,48 @@ __device__ __forceinline__ void pa_store_shade(P *t, uint32_t id, uint32_t prim,
     t[PA_F(4u)] = make_uint4(pfu(sdiffuse.x), pfu(sdiffuse.y), pfu(sdiffuse.z), 0u);
 }
 
+/* a NODE item: two fields in the arena (its position is the node id), three in LDS */
+template <class P>
+__device__ __forceinline__ void pa_store_node(P *t, V3 o, V3 d, uint32_t word, float contribution, uint32_t id) {
+    t[PA_F(0u)] = make_uint4(pfu(o.x), pfu(o.y), pfu(o.z), pfu(d.x));
+    t[PA_F(1u)] = make_uint4(pfu(d.y), pfu(d.z), word, pfu(contribution));
+    if (id != 0xffffffffu) t[PA_F(2u)] = make_uint4(id, 0u, 0u, 0u);
+}
+
+/* all lanes.  Ids for nodes that are not queued in the arena — the roots and the nodes whose items live in LDS — come from
+ * its top, downwards; *overflow when they would meet the queued nodes */
+__device__ __forceinline__ uint32_t pa_top_node(uint32_t *root_alloc, const uint32_t *n_alloc, uint32_t node_cap, bool want, bool *overflow) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    *overflow = false;
+    if (mask == 0ull) return 0u;
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const int leader = (int)__builtin_ctzll(mask);
+    uint32_t base = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(root_alloc, n);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (base + n + lds_load(n_alloc) > node_cap) { *overflow = want; return 0u; }
+    return node_cap - 1u - (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)));
+}
+
+/* the three fields of a REFR item */
+template <class P>
+__device__ __forceinline__ void pa_store_refr(P *t, V3 o, V3 d, uint32_t word, uint32_t parent, uint32_t obj, float contribution, float travel, uint32_t retry) {
+    t[PA_F(0u)] = make_uint4(pfu(o.x), pfu(o.y), pfu(o.z), pfu(d.x));
+    t[PA_F(1u)] = make_uint4(pfu(d.y), pfu(d.z), word, parent);
+    t[PA_F(2u)] = make_uint4(obj, pfu(contribution), pfu(travel), retry);
+}
+
+/* all lanes, after loading a page of an LDS queue: its slot may be written again once the items are in registers.  Pages are
+ * released in the order they were claimed: a wave may wait here for the one before it, which is between its claim and this
+ * point too and has nothing but its own LDS reads to wait for */
+__device__ __forceinline__ void pa_release_page(uint32_t *released, uint32_t page, uint32_t lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0u) {
+        while (lds_load(released) != page) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_store(released, page + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 #ifdef PA_STATS
 /* diagnostic build: wave time by phase (s_memtime ticks, summed over all waves) and chunk / lane counts by item type:
  * [0..3] find work, [4..7] load items, [8..11] the cast, [12..15] after the cast — each by type NODE(0) REFR(1) TILE(2)
@@ -139,6 +194,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
     __shared__ uint4 lds_shade[PA_LDS_PAGES * PA_SHADE_U4 * 64u];
+    __shared__ uint4 lds_refr[PA_LDS_F_PAGES * 3u * 64u];
+    __shared__ uint4 lds_node[PA_LDS_N_PAGES * 3u * 64u];
     const KernelFrame &fr = *pp.frame;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_slots = fr.cols * fr.rows;
@@ -169,6 +226,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         S.l.alloc = S.l.taken = 0u;
         S.l_released = 0u;
         for (uint32_t k = 0; k < PA_LDS_PAGES; ++k) S.ready_l[k] = 0u;
+        S.lf.alloc = S.lf.taken = 0u;
+        S.lf_released = 0u;
+        for (uint32_t k = 0; k < PA_LDS_F_PAGES; ++k) S.ready_lf[k] = 0u;
+        S.ln.alloc = S.ln.taken = 0u;
+        S.ln_released = 0u;
+        for (uint32_t k = 0; k < PA_LDS_N_PAGES; ++k) S.ready_ln[k] = 0u;
         S.root_alloc = 0u;
         S.tiles_exhausted = 0u;
         S.tile_list_count = 0u;
@@ -196,20 +259,19 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         uint32_t type = PA_T_NONE, start = 0u, count = 0u;
         if (lane == 0u) {
             const uint32_t gen = lds_load(&S.gen); /* before looking: a publish during the look must not be slept through */
-            count = pa_claim(&S.n, ready_n, 0xffffffffu, 0u, &start);
-            if (count != 0u) type = PA_T_NODE;
-            if (type == PA_T_NONE) {
-                count = pa_claim(&S.f, ready_f, ring_page_mask, 0u, &start);
+            /* the dependent chains: NODE, then REFR pages (those in LDS first), full ones, then whatever there is */
+            auto claim_chain = [&](uint32_t min_partial) {
+                count = pa_claim(&S.ln, S.ready_ln, PA_LDS_N_PAGES - 1u, min_partial, &start);
+                if (count != 0u) { type = PA_T_NODE | PA_IN_LDS; return; }
+                count = pa_claim(&S.n, ready_n, 0xffffffffu, min_partial, &start);
+                if (count != 0u) { type = PA_T_NODE; return; }
+                count = pa_claim(&S.lf, S.ready_lf, PA_LDS_F_PAGES - 1u, min_partial, &start);
+                if (count != 0u) { type = PA_T_REFR | PA_IN_LDS; return; }
+                count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
                 if (count != 0u) type = PA_T_REFR;
-            }
-            if (PA_CHAIN_PARTIAL_MIN != 0u && type == PA_T_NONE) {
-                count = pa_claim(&S.n, ready_n, 0xffffffffu, PA_CHAIN_PARTIAL_MIN, &start);
-                if (count != 0u) type = PA_T_NODE;
-                if (type == PA_T_NONE) {
-                    count = pa_claim(&S.f, ready_f, ring_page_mask, PA_CHAIN_PARTIAL_MIN, &start);
-                    if (count != 0u) type = PA_T_REFR;
-                }
-            }
+            };
+            claim_chain(0u);
+            if (PA_CHAIN_PARTIAL_MIN != 0u && type == PA_T_NONE) claim_chain(PA_CHAIN_PARTIAL_MIN);
             bool tried_tile = false;
             for (int pass = 0; pass < 2 && type == PA_T_NONE; ++pass) {
                 /* a fresh tile: before SHADE work while little of it is queued (pass 0), else after the full pages (pass 1) */
@@ -236,7 +298,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 }
                 if (type == PA_T_NONE && pass == 0) {
                     count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, 0u, &start);
-                    if (count != 0u) type = PA_T_SHADE_LDS;
+                    if (count != 0u) type = PA_T_SHADE | PA_IN_LDS;
                     if (type == PA_T_NONE) {
                         count = pa_claim(&S.s, ready_s, ring_page_mask, 0u, &start);
                         if (count != 0u) type = PA_T_SHADE;
@@ -248,12 +310,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
              * and may add to it; anything once this wave is the last one awake (then nobody will). */
             for (int last = 0; last < 2 && type == PA_T_NONE; ++last) {
                 const uint32_t min_partial = last ? 1u : PA_MIN_PARTIAL;
-                count = pa_claim(&S.n, ready_n, 0xffffffffu, min_partial, &start);
-                if (count != 0u) { type = PA_T_NODE; break; }
-                count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
-                if (count != 0u) { type = PA_T_REFR; break; }
+                claim_chain(min_partial);
+                if (type != PA_T_NONE) break;
                 count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, min_partial, &start);
-                if (count != 0u) { type = PA_T_SHADE_LDS; break; }
+                if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS; break; }
                 count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
                 if (count != 0u) { type = PA_T_SHADE; break; }
                 if (last) {
@@ -283,8 +343,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         type = (uint32_t)__builtin_amdgcn_readfirstlane((int)type);
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
-        const bool shade_in_lds = type == PA_T_SHADE_LDS;
-        if (shade_in_lds) type = PA_T_SHADE;
+        const bool in_lds = (type & PA_IN_LDS) != 0u;
+        type &= ~PA_IN_LDS;
 #ifdef PA_STATS
         const unsigned long long ph_t1 = PA_TICK();
         if (type == PA_T_NONE) ph[24] += ph_t1 - ph_t0;
@@ -354,12 +414,23 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             type = PA_T_NODE;
             from_tile = true;
         } else if (type == PA_T_NODE) {
-            id = start + lane;
-            /* a sealed page: the positions after its last item are node ids nobody owns; the fold walks all ids below
-             * n.alloc, so they must not look like nodes (level 0 is never folded) */
-            if (!active && id < pp.node_cap) fold_level[id] = 0u;
+            uint4 a, b;
+            a = b = make_uint4(0u, 0u, 0u, 0u);
+            if (in_lds) {
+                if (active) {
+                    const uint4 *t = lds_node + pa_entry((start + lane) & (PA_LDS_N_PAGES * 64u - 1u), 3u);
+                    a = t[PA_F(0u)], b = t[PA_F(1u)];
+                    id = t[PA_F(2u)].x;
+                }
+                pa_release_page(&S.ln_released, start >> 6, lane);
+            } else {
+                id = start + lane;
+                /* a sealed page: the positions after its last item are node ids nobody owns; the fold walks all ids below
+                 * n.alloc, so they must not look like nodes (level 0 is never folded) */
+                if (!active && id < pp.node_cap) fold_level[id] = 0u;
+                if (active) a = node_in[pa_entry(id, 2u)], b = node_in[pa_entry(id, 2u) + PA_F(1u)];
+            }
             if (active) {
-                const uint4 a = node_in[pa_entry(id, 2u)], b = node_in[pa_entry(id, 2u) + PA_F(1u)];
                 req.o = v3(puf(a.x), puf(a.y), puf(a.z));
                 req.d = v3(puf(a.w), puf(b.x), puf(b.y));
                 req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
@@ -368,9 +439,19 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 contribution = puf(b.w);
             }
         } else if (type == PA_T_REFR) {
-            if (active) {
+            uint4 a, b, c;
+            a = b = c = make_uint4(0u, 0u, 0u, 0u);
+            if (in_lds) {
+                if (active) {
+                    const uint4 *t = lds_refr + pa_entry((start + lane) & (PA_LDS_F_PAGES * 64u - 1u), 3u);
+                    a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)];
+                }
+                pa_release_page(&S.lf_released, start >> 6, lane);
+            } else if (active) {
                 const uint4 *t = refr_q + pa_entry((start + lane) & ring_mask, 3u);
-                const uint4 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)];
+                a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)];
+            }
+            if (active) {
                 req.o = v3(puf(a.x), puf(a.y), puf(a.z));
                 req.d = v3(puf(a.w), puf(b.x), puf(b.y));
                 req.mode = (b.z >> PW_MODE_SHIFT) & 3u;
@@ -385,20 +466,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         } else { /* PA_T_SHADE */
             uint4 a, b, c, d, e;
             a = b = c = d = e = make_uint4(0u, 0u, 0u, 0u);
-            if (shade_in_lds) {
+            if (in_lds) {
                 if (active) {
                     const uint4 *t = lds_shade + pa_entry((start + lane) & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4);
                     a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
                 }
-                /* the page's slot may be written again once its items are in registers.  Pages are released in the order they
-                 * were claimed: a wave may wait here for the one before it, which is between its claim and this point too and
-                 * has nothing but its own LDS reads to wait for */
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0u) {
-                    const uint32_t page = start >> 6;
-                    while (lds_load(&S.l_released) != page) __builtin_amdgcn_s_sleep(1);
-                    __hip_atomic_store(&S.l_released, page + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                pa_release_page(&S.l_released, start >> 6, lane);
             } else if (active) {
                 const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
                 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
@@ -470,33 +543,38 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
              * child and the ray into the glass are written and published BEFORE get_shade's preparation below (a normal-map
              * sincos, cgmath's from_arc, a spot light's acos and powf in binary64: about half of this block) — every
              * microsecond here is on the frame's critical path, the SHADE item is not. */
-            const uint32_t k_refl = lds_append(&S.n.alloc, want_refl);
-            const bool overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
+            bool refl_in_lds, overflow;
+            const uint32_t q_refl = pa_try_append(&S.ln, &S.ln_released, PA_LDS_N_PAGES * 64u, want_refl, &refl_in_lds); /* queue position */
+            const uint32_t k_refl = refl_in_lds ? pa_top_node(&S.root_alloc, &S.n.alloc, pp.node_cap, want_refl, &overflow) /* node id */
+                                                : lds_append(&S.n.alloc, want_refl);
+            if (!refl_in_lds) overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
             if (want_refl && !overflow) rec_cr = k_refl;
             if (active) {
                 nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
                 nodes[pa_entry(id, 2u) + PA_F(1u)] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
-                if (!from_tile) fold_level[id] = (unsigned char)((cr.prim >= 0 && depth > 0u) ? depth : 0u); /* roots are folded by tile */
+                fold_level[id] = (unsigned char)((!from_tile && cr.prim >= 0 && depth > 0u) ? depth : 0u); /* roots are folded by tile */
             }
             /* reflection child (get_reflect, main.rs:328-341) */
             if (want_refl && !overflow) {
                 const V3 d = reflect_dir(nh.normal, req.d);
                 const uint32_t word = pack_excl(nh.prim, nh.bf ? FACE_FRONT : FACE_BACK) | (req.mode << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
-                node_in[pa_entry(k_refl, 2u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(d.x));
-                node_in[pa_entry(k_refl, 2u) + PA_F(1u)] = make_uint4(pfu(d.y), pfu(d.z), word, pfu(contribution * rc));
+                if (refl_in_lds) pa_store_node(lds_node + pa_entry(q_refl & (PA_LDS_N_PAGES * 64u - 1u), 3u), nh.pos, d, word, contribution * rc, k_refl);
+                else pa_store_node(node_in + pa_entry(k_refl, 2u), nh.pos, d, word, contribution * rc, 0xffffffffu);
             }
             /* the ray into the glass (main.rs:358-366) */
-            const uint32_t k_refr = lds_append(&S.f.alloc, want_refr);
+            bool refr_in_lds;
+            uint32_t k_refr = pa_try_append(&S.lf, &S.lf_released, PA_LDS_F_PAGES * 64u, want_refr, &refr_in_lds);
+            if (!refr_in_lds) k_refr = lds_append(&S.f.alloc, want_refr);
             if (want_refr) {
-                uint4 *t = refr_q + pa_entry(k_refr & ring_mask, 3u);
                 const uint32_t word = pack_excl(nh.prim, FACE_FRONT) | (FACE_BACK << PW_MODE_SHIFT) | ((depth - 1u) << PW_DEPTH_SHIFT);
-                t[PA_F(0u)] = make_uint4(pfu(nh.pos.x), pfu(nh.pos.y), pfu(nh.pos.z), pfu(inside_d.x));
-                t[PA_F(1u)] = make_uint4(pfu(inside_d.y), pfu(inside_d.z), word, id);
-                t[PA_F(2u)] = make_uint4(nh.obj, pfu(contribution * fc), pfu(0.0f), 0xffffffffu);
+                if (refr_in_lds) pa_store_refr(lds_refr + pa_entry(k_refr & (PA_LDS_F_PAGES * 64u - 1u), 3u), nh.pos, inside_d, word, id, nh.obj, contribution * fc, 0.0f, 0xffffffffu);
+                else pa_store_refr(refr_q + pa_entry(k_refr & ring_mask, 3u), nh.pos, inside_d, word, id, nh.obj, contribution * fc, 0.0f, 0xffffffffu);
             }
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull; /* then the frame is abandoned: nothing to count in */
-            pa_publish(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
-            pa_publish(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
+            if (refl_in_lds) pa_publish(S.ready_ln, PA_LDS_N_PAGES - 1u, want_refl && !any_overflow, q_refl, &S.gen);
+            else pa_publish(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
+            if (refr_in_lds) pa_publish(S.ready_lf, PA_LDS_F_PAGES - 1u, want_refr, k_refr, &S.gen);
+            else pa_publish(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
             /* get_shade up to its first shadow cast (main.rs:407-433) */
             if (want_shade) {
@@ -553,25 +631,29 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     esc_excl = pack_excl(ih.prim, FACE_BACK);
                 }
             }
-            const uint32_t k_again = lds_append(&S.f.alloc, requeue);
+            bool again_in_lds;
+            uint32_t k_again = pa_try_append(&S.lf, &S.lf_released, PA_LDS_F_PAGES * 64u, requeue, &again_in_lds);
+            if (!again_in_lds) k_again = lds_append(&S.f.alloc, requeue);
             if (requeue) {
-                uint4 *t = refr_q + pa_entry(k_again & ring_mask, 3u);
                 const uint32_t word = req.excl | (req.mode << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
-                t[PA_F(0u)] = make_uint4(pfu(req.o.x), pfu(req.o.y), pfu(req.o.z), pfu(req.d.x));
-                t[PA_F(1u)] = make_uint4(pfu(req.d.y), pfu(req.d.z), word, id);
-                t[PA_F(2u)] = make_uint4(obj, pfu(contribution), pfu(travel), (uint32_t)retry);
+                if (again_in_lds) pa_store_refr(lds_refr + pa_entry(k_again & (PA_LDS_F_PAGES * 64u - 1u), 3u), req.o, req.d, word, id, obj, contribution, travel, (uint32_t)retry);
+                else pa_store_refr(refr_q + pa_entry(k_again & ring_mask, 3u), req.o, req.d, word, id, obj, contribution, travel, (uint32_t)retry);
             }
-            const uint32_t k_child = lds_append(&S.n.alloc, escape);
-            const bool overflow = escape && k_child + lds_load(&S.root_alloc) >= pp.node_cap;
+            bool child_in_lds, overflow;
+            const uint32_t q_child = pa_try_append(&S.ln, &S.ln_released, PA_LDS_N_PAGES * 64u, escape, &child_in_lds);
+            const uint32_t k_child = child_in_lds ? pa_top_node(&S.root_alloc, &S.n.alloc, pp.node_cap, escape, &overflow) : lds_append(&S.n.alloc, escape);
+            if (!child_in_lds) overflow = escape && k_child + lds_load(&S.root_alloc) >= pp.node_cap;
             if (escape && !overflow) {
                 const uint32_t word = esc_excl | (FACE_FRONT << PW_MODE_SHIFT) | (depth << PW_DEPTH_SHIFT);
-                node_in[pa_entry(k_child, 2u)] = make_uint4(pfu(esc_o.x), pfu(esc_o.y), pfu(esc_o.z), pfu(esc_d.x));
-                node_in[pa_entry(k_child, 2u) + PA_F(1u)] = make_uint4(pfu(esc_d.y), pfu(esc_d.z), word, pfu(contribution));
+                if (child_in_lds) pa_store_node(lds_node + pa_entry(q_child & (PA_LDS_N_PAGES * 64u - 1u), 3u), esc_o, esc_d, word, contribution, k_child);
+                else pa_store_node(node_in + pa_entry(k_child, 2u), esc_o, esc_d, word, contribution, 0xffffffffu);
                 reinterpret_cast<uint32_t *>(nodes + pa_entry(id, 2u) + PA_F(1u))[3] = k_child; /* record word 7: the refraction child */
             }
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull;
-            pa_publish(ready_f, ring_page_mask, requeue, k_again, &S.gen);
-            pa_publish(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
+            if (again_in_lds) pa_publish(S.ready_lf, PA_LDS_F_PAGES - 1u, requeue, k_again, &S.gen);
+            else pa_publish(ready_f, ring_page_mask, requeue, k_again, &S.gen);
+            if (child_in_lds) pa_publish(S.ready_ln, PA_LDS_N_PAGES - 1u, escape && !any_overflow, q_child, &S.gen);
+            else pa_publish(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
             /* the decay (a powf in binary64) is only read by the fold: after the child is on its way */
             if (escape && !overflow) {
@@ -666,22 +748,26 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     const bool aborted = S.abort != 0u;
     const uint32_t n_nodes = S.n.alloc < pp.node_cap ? S.n.alloc : pp.node_cap; /* the queued nodes; roots sit at the top */
     const uint32_t max_depth = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0);
+    /* the nodes at the top of the arena: the roots (level 0: folded by tile) and the nodes whose items were queued in LDS */
+    const uint32_t n_top = S.root_alloc < pp.node_cap - n_nodes ? S.root_alloc : pp.node_cap - n_nodes;
+    const uint32_t top_first = pp.node_cap - n_top;
     if (!aborted) {
         /* levels 1 .. max_depth-1 (children before parents; level max_depth are the roots, folded by tile below).  Thread t
          * looks after the nodes t, t + 512, t + 1024, ...: neighbouring ids are siblings and cousins of one level, so this
          * spreads a level's nodes evenly over the threads; their level bytes are fetched sixteen at a time */
         for (uint32_t left = 1u; left < max_depth; ++left) {
-            for (uint32_t first = threadIdx.x; first < n_nodes; first += PA_THREADS * 16u) {
+            for (uint32_t first = threadIdx.x; first < n_nodes + n_top; first += PA_THREADS * 16u) {
                 uint32_t lv[16];
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; ++k) {
-                    const uint32_t id = first + k * PA_THREADS;
-                    lv[k] = id < n_nodes ? (uint32_t)fold_level[id] : 0u;
+                    const uint32_t v = first + k * PA_THREADS;
+                    lv[k] = v < n_nodes + n_top ? (uint32_t)fold_level[v < n_nodes ? v : top_first + (v - n_nodes)] : 0u;
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; ++k) {
                     if (lv[k] != left) continue;
-                    const uint32_t id = first + k * PA_THREADS;
+                    const uint32_t v = first + k * PA_THREADS;
+                    const uint32_t id = v < n_nodes ? v : top_first + (v - n_nodes);
                     const uint4 a = nodes[pa_entry(id, 2u)], b = nodes[pa_entry(id, 2u) + PA_F(1u)];
                     const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
                     V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
