@@ -12,7 +12,12 @@
  *   SHADE  one shadow cast of get_shade's light loop (407-464); the item carries the running sum and goes round once
  *          per light that needs a cast, so the lights are still added in order
  *
- * A workgroup (eight waves) owns an arena in HBM with its node records and three queues.  All 64 lanes of a chunk are
+ * A workgroup (eight waves) owns an arena in HBM with its node records and three queues, and keeps the head of each queue
+ * in LDS: a few pages of SHADE, REFR and NODE items (PA_LDS_*_PAGES; 44 KB per workgroup, three workgroups per CU) that
+ * producers fill while there is room and consumers empty first — the arena's rings take only what does not fit, which on
+ * the reference frame is little: 1.0 GB of HBM traffic per 1080p frame instead of 2.5 GB, 1.20 ms instead of 1.28
+ * (profiles/README.md, round 2).  A page's slot is written again only after its consumer has the items in registers
+ * (pa_release_page: pages are released in the order they were claimed).  All 64 lanes of a chunk are
  * in the same phase, so the code between casts runs once; an item is a few dozen bytes, so nothing but the cast's own
  * temporaries is live across the intersection loop (80 VGPRs, six waves per SIMD).  When a workgroup's queues are dry
  * it folds its records bottom-up, value = (shade*sc + reflection*rc) + (refraction*decay)*fc (main.rs:516-518), and
@@ -92,7 +97,9 @@ namespace rt {
 /* A SHADE item is 80 bytes and its consumer evaluates its light again (for a spot light an acos and a powf in binary64).  Twice
  * the light was made to travel with the item instead — as direction + colour in a sixth field (96 B), and as the colour in place
  * of the diffuse colour, which the consumer then re-derived from the material and uv (80 B) — and twice the frame got SLOWER,
- * 1.51 and 1.31 ms against 1.28 (profiles/README.md, round 2): the evaluation runs under the item loads' latency. */
+ * 1.51 and 1.31 ms against 1.28 (profiles/README.md, round 2): evaluating the colour where the item is made spills (95
+ * registers).  A third attempt with the items in LDS — direction and colour evaluated apart, the colour after the other
+ * fields were stored, 8 spills — was as fast as this and no faster (r02_ab15.txt). */
 #define PA_SHADE_U4 5u /* uint4s per SHADE item */
 #ifndef PA_LDS_PAGES
 #define PA_LDS_PAGES 4u /* pages of SHADE items held in LDS (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
