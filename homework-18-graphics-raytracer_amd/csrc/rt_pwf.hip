@@ -102,8 +102,17 @@ namespace rt {
  * fields were stored, 8 spills — was as fast as this and no faster (r02_ab15.txt). */
 #define PA_SHADE_U4 5u /* uint4s per SHADE item */
 #ifndef PA_LDS_PAGES
-#define PA_LDS_PAGES 4u /* pages of SHADE items held in LDS (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
+#define PA_LDS_PAGES 4u /* pages of SHADE items held in LDS PER QUEUE (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
 #endif
+#ifndef PA_LQ
+#define PA_LQ 1u /* SHADE queues in LDS, by the light the item asks next: 0, 1, ..., and PA_LQ - 1 or beyond.  A chunk from one of
+                  * them has ONE light (unless it is the last queue of a scene with more lights): its record comes through scalar
+                  * loads and the code for its kind — a spot light's acos and powf in binary64 — runs only in chunks that need it.
+                  * Measured on the reference frame (three lights): PA_LQ 3 with 2 pages per queue and 2 + 2 pages of REFR and NODE
+                  * items (the same 44 KB) executes 7 % fewer VALU instructions and is 1.5–2 % faster (1.18 against 1.20 ms) but
+                  * sends more items to the arena: 1.22 GB of HBM traffic per frame against 1.00 GB (profiles/r02_ab17…20.txt) */
+#endif
+#define PA_LQ_SHIFT 4u /* type bits 4-5: which of them the claimed page belongs to */
 #ifndef PA_LDS_F_PAGES
 #define PA_LDS_F_PAGES 4u /* the same for REFR items (3 KB each) */
 #endif
@@ -117,9 +126,9 @@ enum : uint32_t { PA_T_NONE = 0u, PA_T_NODE = 1u, PA_T_REFR = 2u, PA_T_TILE = 3u
 
 struct PaShared {
     PaQueue n, f, s;          /* NODE (positions are node ids), REFR ring, SHADE ring */
-    PaQueue l;                /* the SHADE items held in LDS */
-    uint32_t l_released;      /* pages of `l` whose items have been read: their slots may be written again */
-    uint32_t ready_l[PA_LDS_PAGES];
+    PaQueue l[PA_LQ];         /* the SHADE items held in LDS, by light */
+    uint32_t l_released[PA_LQ]; /* pages of `l` whose items have been read: their slots may be written again */
+    uint32_t ready_l[PA_LQ][PA_LDS_PAGES];
     PaQueue lf;               /* the REFR items held in LDS */
     uint32_t lf_released;
     uint32_t ready_lf[PA_LDS_F_PAGES];
@@ -200,7 +209,7 @@ __device__ unsigned long long pa_phase_stats[32];
 __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
-    __shared__ uint4 lds_shade[PA_LDS_PAGES * PA_SHADE_U4 * 64u];
+    __shared__ uint4 lds_shade[PA_LQ * PA_LDS_PAGES * PA_SHADE_U4 * 64u];
     __shared__ uint4 lds_refr[PA_LDS_F_PAGES * 3u * 64u];
     __shared__ uint4 lds_node[PA_LDS_N_PAGES * 3u * 64u];
     const KernelFrame &fr = *pp.frame;
@@ -230,9 +239,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         S.n.alloc = S.n.taken = 0u;
         S.f.alloc = S.f.taken = 0u;
         S.s.alloc = S.s.taken = 0u;
-        S.l.alloc = S.l.taken = 0u;
-        S.l_released = 0u;
-        for (uint32_t k = 0; k < PA_LDS_PAGES; ++k) S.ready_l[k] = 0u;
+        for (uint32_t q = 0; q < PA_LQ; ++q) {
+            S.l[q].alloc = S.l[q].taken = 0u;
+            S.l_released[q] = 0u;
+            for (uint32_t k = 0; k < PA_LDS_PAGES; ++k) S.ready_l[q][k] = 0u;
+        }
         S.lf.alloc = S.lf.taken = 0u;
         S.lf_released = 0u;
         for (uint32_t k = 0; k < PA_LDS_F_PAGES; ++k) S.ready_lf[k] = 0u;
@@ -249,6 +260,25 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     }
     __syncthreads();
     uint32_t casts = 0u;
+    /* all lanes: queue a SHADE item for the lanes that `want` one — in the LDS queue of its light while there is room, else in
+     * the arena's ring */
+    auto queue_shade = [&](bool want, uint32_t id, uint32_t prim, uint32_t word, uint32_t light_i, V3 spos, V3 adj_n, V3 in_dir, V3 sdiffuse, V3 sum) {
+        const uint32_t mine = light_i < PA_LQ - 1u ? light_i : PA_LQ - 1u;
+#pragma unroll
+        for (uint32_t q = 0; q < PA_LQ; ++q) {
+            const bool w = want && mine == q;
+            if (__builtin_amdgcn_ballot_w64(w) == 0ull) continue;
+            bool fits;
+            const uint32_t k = pa_try_append(&S.l[q], &S.l_released[q], PA_LDS_PAGES * 64u, w, &fits);
+            if (!fits) continue;
+            if (w) pa_store_shade(lds_shade + q * (PA_LDS_PAGES * PA_SHADE_U4 * 64u) + pa_entry(k & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
+            pa_publish(S.ready_l[q], PA_LDS_PAGES - 1u, w, k, &S.gen);
+            want = want && !w;
+        }
+        const uint32_t k = lds_append(&S.s.alloc, want);
+        if (want) pa_store_shade(shade_q + pa_entry(k & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
+        pa_publish(ready_s, ring_page_mask, want, k, &S.gen);
+    };
 #ifdef PA_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t st_hist[5] = {0u, 0u, 0u, 0u, 0u}; /* chunks by item count: <= 8, <= 16, <= 32, < 64, 64 */
@@ -277,13 +307,22 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
                 if (count != 0u) type = PA_T_REFR;
             };
+            auto claim_shade = [&](uint32_t min_partial) {
+                for (uint32_t q = 0; q < PA_LQ; ++q) {
+                    count = pa_claim(&S.l[q], S.ready_l[q], PA_LDS_PAGES - 1u, min_partial, &start);
+                    if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS | (q << PA_LQ_SHIFT); return; }
+                }
+                count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
+                if (count != 0u) type = PA_T_SHADE;
+            };
             claim_chain(0u);
             if (PA_CHAIN_PARTIAL_MIN != 0u && type == PA_T_NONE) claim_chain(PA_CHAIN_PARTIAL_MIN);
             bool tried_tile = false;
             for (int pass = 0; pass < 2 && type == PA_T_NONE; ++pass) {
                 /* a fresh tile: before SHADE work while little of it is queued (pass 0), else after the full pages (pass 1) */
                 if (!tried_tile && lds_load(&S.tiles_exhausted) == 0u) {
-                    const uint32_t shade_pages = ((lds_load(&S.s.alloc) >> 6) - lds_load(&S.s.taken)) + ((lds_load(&S.l.alloc) >> 6) - lds_load(&S.l.taken));
+                    uint32_t shade_pages = (lds_load(&S.s.alloc) >> 6) - lds_load(&S.s.taken);
+                    for (uint32_t q = 0; q < PA_LQ; ++q) shade_pages += (lds_load(&S.l[q].alloc) >> 6) - lds_load(&S.l[q].taken);
                     if (pass == 1 || (int32_t)shade_pages < (int32_t)PA_SHADE_PAGES) {
                         tried_tile = true;
                         const uint32_t used = lds_load(&S.n.alloc) + lds_load(&S.root_alloc);
@@ -303,14 +342,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         }
                     }
                 }
-                if (type == PA_T_NONE && pass == 0) {
-                    count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, 0u, &start);
-                    if (count != 0u) type = PA_T_SHADE | PA_IN_LDS;
-                    if (type == PA_T_NONE) {
-                        count = pa_claim(&S.s, ready_s, ring_page_mask, 0u, &start);
-                        if (count != 0u) type = PA_T_SHADE;
-                    }
-                }
+                if (type == PA_T_NONE && pass == 0) claim_shade(0u);
             }
             /* Partly filled pages: waiting for them to fill would hold up the chains behind their items, but a page taken
              * with a handful of items costs a full intersection loop.  Half a page at least while other waves are awake
@@ -319,10 +351,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 const uint32_t min_partial = last ? 1u : PA_MIN_PARTIAL;
                 claim_chain(min_partial);
                 if (type != PA_T_NONE) break;
-                count = pa_claim(&S.l, S.ready_l, PA_LDS_PAGES - 1u, min_partial, &start);
-                if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS; break; }
-                count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
-                if (count != 0u) { type = PA_T_SHADE; break; }
+                claim_shade(min_partial);
+                if (type != PA_T_NONE) break;
                 if (last) {
                     /* the last wave awake found nothing whatsoever: the queues are final.  (Idle waves stay counted while
                      * they sleep, so the count is still PA_WAVES - 1 unless one has just been woken by new items.) */
@@ -351,7 +381,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
         count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
         const bool in_lds = (type & PA_IN_LDS) != 0u;
-        type &= ~PA_IN_LDS;
+        const uint32_t lq = (type >> PA_LQ_SHIFT) & 3u; /* SHADE pages in LDS: the queue, i.e. the light */
+        type &= 7u;
+        const bool one_light = type == PA_T_SHADE && in_lds && (lq < PA_LQ - 1u || sc.n_lights <= PA_LQ);
 #ifdef PA_STATS
         const unsigned long long ph_t1 = PA_TICK();
         if (type == PA_T_NONE) ph[24] += ph_t1 - ph_t0;
@@ -475,10 +507,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             a = b = c = d = e = make_uint4(0u, 0u, 0u, 0u);
             if (in_lds) {
                 if (active) {
-                    const uint4 *t = lds_shade + pa_entry((start + lane) & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4);
+                    const uint4 *t = lds_shade + lq * (PA_LDS_PAGES * PA_SHADE_U4 * 64u) + pa_entry((start + lane) & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4);
                     a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
                 }
-                pa_release_page(&S.l_released, start >> 6, lane);
+                pa_release_page(&S.l_released[lq], start >> 6, lane);
             } else if (active) {
                 const uint4 *t = shade_q + pa_entry((start + lane) & ring_mask, PA_SHADE_U4);
                 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
@@ -489,7 +521,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 adj_n = v3(puf(c.x), puf(c.y), puf(c.z)); sum.y = puf(c.w);
                 in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
                 sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z));
-                do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl); /* always true for a queued item */
+                /* always true for a queued item: its light asks for a cast */
+                if (one_light) do_cast = approximate_into_directional(sc.lights[lq], spos, &dl);
+                else do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl);
                 req.o = spos;
                 req.d = -dl.direction;
                 req.mode = FACE_BACK;
@@ -557,7 +591,6 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             if (!refl_in_lds) overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
             if (want_refl && !overflow) rec_cr = k_refl;
             if (active) {
-                nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
                 nodes[pa_entry(id, 2u) + PA_F(1u)] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
                 fold_level[id] = (unsigned char)((!from_tile && cr.prim >= 0 && depth > 0u) ? depth : 0u); /* roots are folded by tile */
             }
@@ -590,22 +623,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 adj_n = adjust_normal(m.normal, nh.normal); /* main.rs:410 */
                 sdiffuse = m.diffuse;
                 light_i = 0u;
-                want_shade = next_shadow_ray(sc, &light_i, nh.pos, adj_n, &dl); /* no light needs a cast: get_shade = black */
             }
-            {
-                const uint32_t word = nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u);
-                const V3 zero = v3(0.0f, 0.0f, 0.0f);
-                bool in_lds;
-                uint32_t k_shade = pa_try_append(&S.l, &S.l_released, PA_LDS_PAGES * 64u, want_shade, &in_lds);
-                if (in_lds) {
-                    if (want_shade) pa_store_shade(lds_shade + pa_entry(k_shade & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, nh.prim, word, nh.pos, adj_n, req.d, sdiffuse, zero);
-                    pa_publish(S.ready_l, PA_LDS_PAGES - 1u, want_shade, k_shade, &S.gen);
-                } else {
-                    k_shade = lds_append(&S.s.alloc, want_shade);
-                    if (want_shade) pa_store_shade(shade_q + pa_entry(k_shade & ring_mask, PA_SHADE_U4), id, nh.prim, word, nh.pos, adj_n, req.d, sdiffuse, zero);
-                    pa_publish(ready_s, ring_page_mask, want_shade, k_shade, &S.gen);
-                }
-            }
+            want_shade = next_shadow_ray_in_step(sc, 0u, want_shade, &light_i, nh.pos, adj_n); /* no light needs a cast: get_shade = black */
+            /* the record's first field (shade term, rc): written here unless a SHADE item will, with the term filled in */
+            if (active && !want_shade) nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
+            queue_shade(want_shade, id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), light_i, nh.pos, adj_n, req.d, sdiffuse,
+                        v3(0.0f, 0.0f, 0.0f));
         } else if (type == PA_T_REFR) {
             /* ---- one step of get_refract (main.rs:371-403) ---- */
             bool requeue = false, escape = false;
@@ -673,18 +696,17 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             if (active) {
                 const rt_material &rm = sc.materials[obj];
                 if (do_cast) {
-                    const rt_light &L = sc.lights[light_i];
                     bool lit = true;
                     if (cr.prim >= 0) {
-                        const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
-                        if (has_origin) {
+                        auto occluded = [&](const rt_light &L) {
+                            const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
+                            if (!has_origin) return true;
                             const V3 occ = req.o + req.d * cr.t;
                             const float occlusion_distance = distance(spos, occ);
                             const float light_distance = distance(spos, v3(L.origin[0], L.origin[1], L.origin[2]));
-                            if (occlusion_distance < light_distance) lit = false;
-                        } else {
-                            lit = false;
-                        }
+                            return occlusion_distance < light_distance;
+                        };
+                        lit = one_light ? !occluded(sc.lights[lq]) : !occluded(sc.lights[light_i]);
                     }
                     if (lit) { /* main.rs:450-461 */
                         Mat m;
@@ -703,33 +725,24 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
                     }
                     light_i += 1u;
-                    again = next_shadow_ray(sc, &light_i, spos, adj_n, &dl);
+                    if (!one_light) again = next_shadow_ray(sc, &light_i, spos, adj_n, &dl);
                 }
+            }
+            if (one_light) again = next_shadow_ray_in_step(sc, lq + 1u, active && do_cast, &light_i, spos, adj_n);
+            if (active) {
+                const rt_material &rm = sc.materials[obj];
                 if (!again) {
                     V3 acc = sum; /* depth 0: the unscaled shade (main.rs:488-490) */
+                    float rc = 0.0f;
                     if (sflags == 0u) {
                         const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
                         acc = sum * shade_contribution;
+                        rc = rm.shiness * (1.0f - rm.transparency); /* main.rs:493, as the node's own step has it */
                     }
-                    float *rec = reinterpret_cast<float *>(nodes + pa_entry(id, 2u));
-                    rec[0] = acc.x;
-                    rec[1] = acc.y;
-                    rec[2] = acc.z;
+                    nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
                 }
             }
-            {
-                const uint32_t word = obj | (light_i << 16) | (sflags << 31);
-                bool in_lds;
-                uint32_t k_again = pa_try_append(&S.l, &S.l_released, PA_LDS_PAGES * 64u, again, &in_lds);
-                if (in_lds) {
-                    if (again) pa_store_shade(lds_shade + pa_entry(k_again & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
-                    pa_publish(S.ready_l, PA_LDS_PAGES - 1u, again, k_again, &S.gen);
-                } else {
-                    k_again = lds_append(&S.s.alloc, again);
-                    if (again) pa_store_shade(shade_q + pa_entry(k_again & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
-                    pa_publish(ready_s, ring_page_mask, again, k_again, &S.gen);
-                }
-            }
+            queue_shade(again, id, prim, obj | (light_i << 16) | (sflags << 31), light_i, spos, adj_n, in_dir, sdiffuse, sum);
         }
 #ifdef PA_STATS
         {

@@ -146,6 +146,23 @@ __device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t 
     return false;
 }
 
+/* all lanes.  The same search with the wave in step: every lane that is still `searching` asks light `first`, then first + 1,
+ * ... (first is wave-uniform, so each light's record comes through scalar loads and only the code for its kind runs) */
+__device__ __forceinline__ bool next_shadow_ray_in_step(const KernelScene &sc, uint32_t first, bool searching, uint32_t *light_i, V3 pos, V3 adj_n) {
+    bool found = false;
+    for (uint32_t li = first; li < sc.n_lights; ++li) {
+        if (__builtin_amdgcn_ballot_w64(searching) == 0ull) break;
+        DirLight dl;
+        const bool asks = approximate_into_directional(sc.lights[li], pos, &dl) && !(-dot(dl.direction, adj_n) <= 0.0f);
+        if (searching && asks) {
+            *light_i = li;
+            found = true;
+            searching = false;
+        }
+    }
+    return found;
+}
+
 } /* namespace rt */
 
 #endif /* RT_PWF_COMMON_H */
