@@ -38,8 +38,16 @@ void math_eval_host(int op, const float *x, const float *y, float *out, size_t n
  * their own.  Grow-only; allocated on the first call that needs it (not inside a graph capture). */
 struct Workspace {
     uint32_t *d_counters = nullptr; /* [0] the stochastic pass's chunk counter */
-    void *d_pwf = nullptr; /* persistent-wavefront path: global words + one arena per workgroup */
+    void *d_pwf = nullptr; /* persistent-wavefront path: two blocks of global words, the frame description, one arena per workgroup */
     size_t pwf_bytes = 0;
+    /* Launches on this workspace alternate between the two blocks of global words: a launch's last workgroup zeroes the
+     * other block, so the next launch needs no preparation of its own unless its frame description differs from what is in
+     * device memory (or nothing has run here yet). */
+    uint32_t pw_parity = 0;
+    bool pw_ready = false;
+    bool pw_always_prepare = false; /* a call on this stream was captured into a graph: replays come unannounced, so from then on
+                                     * every launch prepares its own block and frame description, as a captured one does */
+    rt::KernelFrame pw_frame;
     void *d_split = nullptr; /* split distributed pass: requests, shades and frames of one batch of epochs */
     size_t split_bytes = 0;
     void *d_chainq = nullptr; /* queued chain kernel: one arena of item rings per resident workgroup */
@@ -615,7 +623,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     const int wf_budget = current_wf_budget();
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);
-    uint32_t pw_groups = 0, pw_band_rows = 0;
+    uint32_t pw_groups = 0, pw_band_rows = 0, pw_parity = 0;
+    bool pw_init = true;
     rt::KernelQueues qs;
     memset(&qs, 0, sizeof qs);
     {
@@ -652,11 +661,12 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             pw.node_cap = (uint32_t)(ring - 1024u);
             pw.tile_reserve = 10;
             pw.arena_stride = (rt::pwf_arena_bytes(pw.node_cap, pw.ring_cap) + 255u) & ~(size_t)255u;
-            const size_t need = 256 + (size_t)groups * pw.arena_stride;
+            const size_t need = 512 + (size_t)groups * pw.arena_stride;
             if (need > ws.pwf_bytes) {
                 if (ws.d_pwf) (void)hipFree(ws.d_pwf);
                 ws.d_pwf = nullptr;
                 ws.pwf_bytes = 0;
+                ws.pw_ready = false;
                 const char *refuse = getenv("RT_AMD_DIAG_WS_REFUSE"); /* test hook: pretend the allocation fails */
                 if ((refuse && atoi(refuse) > 0) || hipMalloc(&ws.d_pwf, need) != hipSuccess) {
                     (void)hipGetLastError();
@@ -667,11 +677,30 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             }
             if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
             pw.tile_order = g_diag_tile_order.load();
-            pw.global = static_cast<uint32_t *>(ws.d_pwf);
-            pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 128);
+            static_assert(PW_G_BLOCK_WORDS * sizeof(uint32_t) == 128, "two blocks of global words and the frame description share the 512-byte header");
             static_assert(sizeof(rt::KernelFrame) <= 128, "the frame description must fit its slot of the workspace header");
-            pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 256;
+            pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 256);
+            pw.arena = static_cast<unsigned char *>(ws.d_pwf) + 512;
+            pw.ray_count = d_ray_count;
             pw_groups = (uint32_t)groups;
+            if (ws.d_pwf != nullptr) {
+                hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) (void)hipGetLastError();
+                if (capturing != hipStreamCaptureStatusNone) ws.pw_always_prepare = true;
+                if (pw_band_rows >= kf.rows && !ws.pw_always_prepare) { /* one launch: does it find its block zeroed and its frame description in place? */
+                    rt::KernelFrame want_frame = kf;
+                    want_frame.n_chunks = (kf.cols * kf.rows + 63u) / 64u; /* as launch_pwf fills it in */
+                    pw_init = !ws.pw_ready || memcmp(&ws.pw_frame, &want_frame, sizeof want_frame) != 0;
+                    pw_parity = ws.pw_parity;
+                    ws.pw_parity ^= 1u;
+                    ws.pw_frame = want_frame;
+                    ws.pw_ready = true;
+                } else { /* several bands, each with its own frame description: every launch prepares its own */
+                    pw_init = true;
+                    pw_parity = 0;
+                    ws.pw_ready = false;
+                }
+            }
         }
 #ifdef RT_DIAG_TIMELINE
         qs.timeline = g_diag_timeline;
@@ -693,6 +722,9 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     hipError_t e = hipSuccess;
     if (variant & RT_VARIANT_PWF) {
         /* a band that does not fit the arenas is rendered by the per-pixel kernel instead (a no-op otherwise) */
+        uint32_t *const blocks = reinterpret_cast<uint32_t *>(const_cast<unsigned char *>(pw.arena) - 512);
+        pw.global = blocks + pw_parity * PW_G_BLOCK_WORDS;
+        pw.global_next = blocks + (pw_parity ^ 1u) * PW_G_BLOCK_WORDS;
         qs.run_if = pw.global + PW_G_OVERFLOW;
         for (uint32_t r0 = 0; e == hipSuccess && r0 < kf.rows; r0 += pw_band_rows) {
             rt::KernelFrame band = kf;
@@ -708,14 +740,19 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 pw.tile_stride = (uint32_t)stride;
             }
             const bool first = r0 == 0, last = r0 + pw_band_rows >= kf.rows;
-            e = rt::launch_pwf(scene->ks, band, band_rgb, d_ray_count, pw, pw_groups, stream, first, last);
+            e = rt::launch_pwf(scene->ks, band, band_rgb, pw, pw_groups, stream, pw_init, first, last);
             if (e == hipSuccess) {
                 rt::mute_main_kernel_events(true); /* the event pair brackets the persistent kernel(s), not the fallback */
                 e = rt::launch_whitted(scene->ks, band, band_rgb, d_ray_count, qs, stream, (variant & RT_VARIANT_LDS) | RT_VARIANT_STATIC);
                 rt::mute_main_kernel_events(false);
             }
         }
-        if (e != hipSuccess) return fail_hip("rt_render_whitted: launch", e);
+        if (e != hipSuccess) {
+            rt_scene *mut = const_cast<rt_scene *>(scene);
+            std::lock_guard<std::mutex> lock(mut->ws_mutex);
+            mut->workspaces[stream].pw_ready = false; /* whatever state the blocks are in: the next launch prepares its own */
+            return fail_hip("rt_render_whitted: launch", e);
+        }
         return RT_OK;
     }
     e = rt::launch_whitted(scene->ks, kf, d_rgb, d_ray_count, qs, stream, variant);

@@ -22,6 +22,7 @@
 #else
 #define RT_LAUNCH_BOUNDS __launch_bounds__(RT_BLOCK_THREADS)
 #endif
+#define RT_FALLBACK_WAVES 4096u /* grid of the wavefront path's fallback launch of the per-pixel kernel (rt_kernels.hip) */
 #define RT_LDS_SCENE_LIMIT (96u * 1024u) /* triangle records staged in LDS up to this many bytes */
 
 /* kernel variants (A/B-selectable through RT_AMD_VARIANT or rt_set_variant): 2, 3, 18 (default), 19 */
@@ -82,11 +83,15 @@ hipError_t launch_whitted(const KernelScene &sc, const KernelFrame &fr, float *o
 #define PW_G_TILE 0u       /* next tile of the frame */
 #define PW_G_OVERFLOW 1u   /* the frame could not be finished within the arenas: the per-pixel kernel renders it */
 #define PW_G_TILES_DONE 2u /* tiles whose pixels were written */
+#define PW_G_GROUPS_DONE 3u /* workgroups that have left the kernel: the last one closes the frame */
 #define PW_G_CASTS 4u      /* u64 */
 #define PW_G_WORDS 8u
+#define PW_G_BLOCK_WORDS 32u /* a block of global words (PW_G_WORDS of them in use, the rest for diagnostic builds) */
 struct PwParams {
-    uint32_t *global;       /* PW_G_WORDS u32, initialised by the launch */
-    const KernelFrame *frame; /* the frame description, in device memory (filled by the launch) */
+    uint32_t *global;       /* this launch's block of PW_G_BLOCK_WORDS u32: zero when the kernel starts */
+    uint32_t *global_next;  /* the next launch's block: the last workgroup of this one zeroes it */
+    unsigned long long *ray_count; /* += the frame's casts when it was finished within the arenas; may be null */
+    const KernelFrame *frame; /* the frame description, in device memory */
     unsigned char *arena;   /* one arena of arena_stride bytes per workgroup */
     size_t arena_stride;
     uint32_t node_cap;      /* nodes per arena */
@@ -97,8 +102,11 @@ struct PwParams {
 };
 int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap);
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap);
-hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream, bool first_band, bool last_band);
+/* init: zero this launch's block of global words and (re)write the frame description first — needed for a workspace's first
+ * launch and whenever the frame description differs from the previous launch's; otherwise the previous launch has left
+ * both as this one needs them */
+hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const PwParams &pp, uint32_t workgroups, hipStream_t stream,
+                      bool init, bool first_band, bool last_band);
 
 /* distributed pass (rt_distributed.hip) */
 struct DistParams {

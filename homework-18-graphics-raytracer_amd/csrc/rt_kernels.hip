@@ -68,25 +68,13 @@ struct Frame {
  * when the persistent wavefront kernel of rt_pwf.hip had long been the default and this kernel its fallback.) */
 template <int MAXD, bool USE_LDS>
 __device__ __forceinline__ void whitted_body(const KernelScene &sc, const KernelFrame &fr, float *__restrict__ out,
-                                             unsigned long long *__restrict__ ray_count, const KernelQueues &qs) {
-    if (qs.run_if != nullptr && *qs.run_if == 0u) return; /* fallback launch that is not needed */
-    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
-    const DevTri *lds_tris = nullptr;
-    if (USE_LDS) {
-        /* stage the triangle records once per workgroup: coalesced 16-byte loads, then broadcast reads */
-        const uint32_t n16 = sc.n_triangles * (uint32_t)(sizeof(DevTri) / 16);
-        const uint4 *src = reinterpret_cast<const uint4 *>(sc.tris);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-        lds_tris = reinterpret_cast<const DevTri *>(lds_raw);
-    }
+                                             unsigned long long *__restrict__ ray_count, const KernelQueues &qs, const DevTri *lds_tris,
+                                             const uint32_t wave) {
 
     /* Work assignment.  The tile image (cols x rows) is enumerated as "slots": 8-row bands, column-major
      * inside a band, so 64 consecutive slots are an 8x8 pixel block (8 x fewer rows in a ragged last band).
      * Wave w owns slots [64 w, 64 w + 64). */
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 #ifdef RT_DIAG_TIMELINE /* diagnostic build only: wave start/end on the 100 MHz constant clock, iterations, HW id */
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
@@ -447,7 +435,24 @@ __device__ __forceinline__ void whitted_body(const KernelScene &sc, const Kernel
 template <int MAXD, bool USE_LDS>
 __global__ RT_LAUNCH_BOUNDS void whitted_kernel(const KernelScene sc, const KernelFrame fr, float *__restrict__ out,
                                                 unsigned long long *__restrict__ ray_count, const KernelQueues qs) {
-    whitted_body<MAXD, USE_LDS>(sc, fr, out, ray_count, qs);
+    if (qs.run_if != nullptr && *qs.run_if == 0u) return; /* fallback launch that is not needed */
+    extern __shared__ __attribute__((aligned(128))) unsigned char lds_raw[];
+    const DevTri *lds_tris = nullptr;
+    if (USE_LDS) {
+        /* stage the triangle records once per workgroup: coalesced 16-byte loads, then broadcast reads */
+        const uint32_t n16 = sc.n_triangles * (uint32_t)(sizeof(DevTri) / 16);
+        const uint4 *src = reinterpret_cast<const uint4 *>(sc.tris);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        lds_tris = reinterpret_cast<const DevTri *>(lds_raw);
+    }
+    /* one tile per wave when the grid covers the frame (the per-pixel render paths); the wavefront path's fallback launch is
+     * a small grid — it usually has nothing to do, and 32 K workgroups that leave at once cost 7 us — whose waves take
+     * tiles a grid apart */
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < fr.n_chunks; wave += n_waves)
+        whitted_body<MAXD, USE_LDS>(sc, fr, out, ray_count, qs, lds_tris, wave);
 }
 
 } /* namespace rt */
@@ -489,7 +494,9 @@ static hipError_t launch_maxd(const KernelScene &sc, KernelFrame fr, float *out,
     const uint32_t total = fr.cols * fr.rows;
     fr.n_chunks = (total + 63u) / 64u;
     record_main_kernel_event(0, stream);
-    const hipError_t e = launch_tiles<MAXD>(sc, fr, out, ray_count, qs, fr.n_chunks, stream, use_lds);
+    uint32_t waves = fr.n_chunks;
+    if (qs.run_if != nullptr && waves > RT_FALLBACK_WAVES) waves = RT_FALLBACK_WAVES;
+    const hipError_t e = launch_tiles<MAXD>(sc, fr, out, ray_count, qs, waves, stream, use_lds);
     record_main_kernel_event(1, stream);
     return e;
 }

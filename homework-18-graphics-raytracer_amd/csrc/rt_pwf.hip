@@ -885,6 +885,27 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
 #endif
     for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
     if (lane == 0u && casts != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), (unsigned long long)casts);
+
+    /* ---- the last workgroup to leave closes the frame (no launch of its own for that): every tile rendered and no arena
+     * overflow -> publish the cast count; else raise the flag the trailing per-pixel launch looks at.  And it zeroes the
+     * block of global words the NEXT launch on this workspace will use (this launch's block stays as it is until then: the
+     * per-pixel launch reads the flag from it). ---- */
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        if (atomicAdd(pp.global + PW_G_GROUPS_DONE, 1u) + 1u == gridDim.x) {
+            __threadfence();
+            uint32_t overflow = __hip_atomic_load(pp.global + PW_G_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tiles_done = __hip_atomic_load(pp.global + PW_G_TILES_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (overflow == 0u && tiles_done != n_tiles) {
+                overflow = 1u;
+                atomicExch(pp.global + PW_G_OVERFLOW, 1u);
+            }
+            if (overflow == 0u && pp.ray_count != nullptr)
+                *pp.ray_count += __hip_atomic_load(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t k = 0; k < PW_G_BLOCK_WORDS; ++k) pp.global_next[k] = 0u;
+        }
+    }
 }
 
 int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap) {
@@ -895,14 +916,8 @@ int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap) {
 }
 
 __global__ void pwf_init_kernel(uint32_t *global, KernelFrame *frame, const KernelFrame fr) {
-    if (threadIdx.x < 32u) global[threadIdx.x] = 0u; /* PW_G_WORDS, plus the diagnostic words of PA_STATS builds */
+    if (threadIdx.x < PW_G_BLOCK_WORDS) global[threadIdx.x] = 0u;
     if (threadIdx.x == 0u) *frame = fr;
-}
-
-/* every tile rendered and no arena overflow: publish the cast count; else raise the flag the fallback launch looks at */
-__global__ void pwf_finish_kernel(uint32_t *global, uint32_t n_tiles, unsigned long long *ray_count) {
-    if (global[PW_G_OVERFLOW] == 0u && global[PW_G_TILES_DONE] != n_tiles) global[PW_G_OVERFLOW] = 1u;
-    if (global[PW_G_OVERFLOW] == 0u && ray_count != nullptr) *ray_count += *reinterpret_cast<const unsigned long long *>(global + PW_G_CASTS);
 }
 
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap) {
@@ -928,20 +943,19 @@ extern "C" int rt_diag_read_pwf_phases(unsigned long long *out32, int reset) {
 }
 #endif
 
-hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, unsigned long long *ray_count, const PwParams &pp,
-                      uint32_t workgroups, hipStream_t stream, bool first_band, bool last_band) {
+hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const PwParams &pp, uint32_t workgroups, hipStream_t stream,
+                      bool init, bool first_band, bool last_band) {
     const uint32_t total = fr.cols * fr.rows;
     fr.n_chunks = (total + 63u) / 64u;
     if (total == 0u) return hipSuccess;
 #ifdef PA_STATS
     g_pw_last_global = pp.global;
 #endif
-    hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
+    if (init) hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     if (first_band) record_main_kernel_event(0, stream); /* the pair brackets all bands of a call (one, up to ~8 Mpixel) */
     const size_t lds = (size_t)((pp.node_cap + 63u) / 64u + 2u * (pp.ring_cap / 64u)) * sizeof(uint32_t);
     hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
     if (last_band) record_main_kernel_event(1, stream);
-    hipLaunchKernelGGL(pwf_finish_kernel, dim3(1), dim3(1), 0, stream, pp.global, fr.n_chunks, ray_count);
     return hipGetLastError();
 }
 

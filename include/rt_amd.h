@@ -22,6 +22,14 @@
  * under a lock; the rt_set_* settings are atomics; the profiling hooks keep the
  * event pair of a call in thread-local state).  Calls on ONE stream, and calls
  * on one rt_rng, must be serialised by the caller.
+ *
+ * State between calls: the per-(scene, stream) workspace remembers which frame
+ * description it holds on the device, so that a call with the same frame as the
+ * one before it is a single kernel launch.  A render call may be captured into a
+ * HIP graph once its workspace exists (allocation cannot be captured: render the
+ * frame once uncaptured first); from the first capture on a stream, every
+ * launch on that stream prepares its own state, as the captured one does, since
+ * replays come unannounced.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
