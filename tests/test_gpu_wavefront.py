@@ -249,3 +249,75 @@ def test_no_memory_for_the_arenas_means_the_per_pixel_kernel(ref):
         _check(world, cam, rt.Frame.full(200, 150, 6), scene=rt.Scene(world))
     finally:
         del os.environ["RT_AMD_DIAG_WS_REFUSE"]
+
+
+def _mismatches(got, want):
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))  # as in _check
+    return int((~same).sum())
+
+
+def test_state_between_calls_on_one_stream(ref):
+    """A workspace keeps the frame description and a zeroed block of counters from one call to the next (rt_api.hip: the
+    kernel's last workgroup closes the frame and prepares the next launch).  Alternate frames, let one overflow into the
+    per-pixel kernel in between, and come back: every image and every cast count as on a fresh stream."""
+    import torch
+
+    world, cam, scene = ref
+    lib = _capi.amd_lib()
+    frames = [rt.Frame.full(320, 200, 8), rt.Frame.full(160, 120, 5), rt.Frame(640, 400, 8, 64, 32, 64 + 320, 32 + 200, 1)]
+    want = []
+    for f in frames:
+        w, c = _oracle.render_whitted(world.desc(), cam, f)
+        want.append((w, c))
+    stream = torch.cuda.Stream()
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    order = [0, 0, 1, 0, 2, 2, 1, 1, 0]
+    with torch.cuda.stream(stream):
+        for step, k in enumerate(order):
+            if step == 4:  # an overflowing frame in between: budget 1 hands it to the per-pixel kernel
+                _capi.check(lib.rt_set_wavefront_budget(1))
+            count.zero_()
+            got = rt.render_whitted(scene, cam, frames[k], ray_count=count, stream=stream)
+            if step == 4:
+                _capi.check(lib.rt_set_wavefront_budget(6))
+            stream.synchronize()
+            bad = _mismatches(got.cpu().numpy(), want[k][0])
+            assert bad == 0, f"step {step}: frame {k}: {bad} channels differ"
+            assert int(count.item()) == want[k][1], f"step {step}: frame {k}"
+
+
+def test_captured_call_replays_between_direct_calls(ref):
+    """include/rt_amd.h "State between calls": a render call captured into a graph prepares its own state, and so does
+    every later launch on that stream — replays and direct calls with other frames may alternate."""
+    import torch
+
+    world, cam, scene = ref
+    fa, fb = rt.Frame.full(256, 160, 8), rt.Frame.full(200, 96, 4)
+    wa, ca = _oracle.render_whitted(world.desc(), cam, fa)
+    wb, cb = _oracle.render_whitted(world.desc(), cam, fb)
+    stream = torch.cuda.Stream()
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    out_a = torch.empty((fa.rows, fa.cols, 3), dtype=torch.float32, device="cuda")
+    with torch.cuda.stream(stream):
+        rt.render_whitted(scene, cam, fa, out=out_a, stream=stream)  # the workspace exists before the capture
+        rt.render_whitted(scene, cam, fa, out=out_a, stream=stream)  # ... and is in its steady state
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        rt.render_whitted(scene, cam, fa, out=out_a, ray_count=count, stream=torch.cuda.current_stream())
+    for step in range(6):
+        if step % 2 == 0:
+            out_a.zero_()
+            count.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert _mismatches(out_a.cpu().numpy(), wa) == 0, f"replay at step {step}"
+            assert int(count.item()) == ca
+        else:
+            with torch.cuda.stream(stream):
+                count.zero_()
+                got = rt.render_whitted(scene, cam, fb if step != 3 else fa, ray_count=count, stream=stream)
+            stream.synchronize()
+            w, c = (wb, cb) if step != 3 else (wa, ca)
+            assert _mismatches(got.cpu().numpy(), w) == 0, f"direct call at step {step}"
+            assert int(count.item()) == c
