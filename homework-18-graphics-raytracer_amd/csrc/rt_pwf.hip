@@ -206,6 +206,7 @@ __device__ unsigned long long pa_phase_stats[32];
 
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read once per tile, and as a
  * by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
+template <bool PACKED> /* the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels */
 __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
@@ -231,10 +232,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
      * 16-byte aligned because tile_cap * 8 bytes is a multiple of 16 only for even tile_cap */
     unsigned char *fold_level = reinterpret_cast<unsigned char *>(((uintptr_t)(tile_list + (size_t)tile_cap * 2u) + 15u) & ~(uintptr_t)15u);
     const uint32_t node_pages = (pp.node_cap + 63u) / 64u, ring_pages = pp.ring_cap / 64u;
-    uint32_t *ready_n = pa_ready, *ready_s = pa_ready + node_pages, *ready_f = ready_s + ring_pages;
+    uint32_t *ready_n = pa_ready, *ready_s = pa_ready + PA_READY_WORDS(node_pages, PACKED), *ready_f = ready_s + PA_READY_WORDS(ring_pages, PACKED);
     const uint32_t ring_page_mask = ring_pages - 1u;
 
-    for (uint32_t i = threadIdx.x; i < node_pages + 2u * ring_pages; i += PA_THREADS) pa_ready[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < PA_READY_WORDS(node_pages, PACKED) + 2u * PA_READY_WORDS(ring_pages, PACKED); i += PA_THREADS) pa_ready[i] = 0u;
     if (threadIdx.x == 0u) {
         S.n.alloc = S.n.taken = 0u;
         S.f.alloc = S.f.taken = 0u;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         }
         const uint32_t k = lds_append(&S.s.alloc, want);
         if (want) pa_store_shade(shade_q + pa_entry(k & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
-        pa_publish(ready_s, ring_page_mask, want, k, &S.gen);
+        pa_publish<PACKED>(ready_s, ring_page_mask, want, k, &S.gen);
     };
 #ifdef PA_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
@@ -300,11 +301,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             auto claim_chain = [&](uint32_t min_partial) {
                 count = pa_claim(&S.ln, S.ready_ln, PA_LDS_N_PAGES - 1u, min_partial, &start);
                 if (count != 0u) { type = PA_T_NODE | PA_IN_LDS; return; }
-                count = pa_claim(&S.n, ready_n, 0xffffffffu, min_partial, &start);
+                count = pa_claim<PACKED>(&S.n, ready_n, 0xffffffffu, min_partial, &start);
                 if (count != 0u) { type = PA_T_NODE; return; }
                 count = pa_claim(&S.lf, S.ready_lf, PA_LDS_F_PAGES - 1u, min_partial, &start);
                 if (count != 0u) { type = PA_T_REFR | PA_IN_LDS; return; }
-                count = pa_claim(&S.f, ready_f, ring_page_mask, min_partial, &start);
+                count = pa_claim<PACKED>(&S.f, ready_f, ring_page_mask, min_partial, &start);
                 if (count != 0u) type = PA_T_REFR;
             };
             auto claim_shade = [&](uint32_t min_partial) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                     count = pa_claim(&S.l[q], S.ready_l[q], PA_LDS_PAGES - 1u, min_partial, &start);
                     if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS | (q << PA_LQ_SHIFT); return; }
                 }
-                count = pa_claim(&S.s, ready_s, ring_page_mask, min_partial, &start);
+                count = pa_claim<PACKED>(&S.s, ready_s, ring_page_mask, min_partial, &start);
                 if (count != 0u) type = PA_T_SHADE;
             };
             claim_chain(0u);
@@ -612,9 +613,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull; /* then the frame is abandoned: nothing to count in */
             if (refl_in_lds) pa_publish(S.ready_ln, PA_LDS_N_PAGES - 1u, want_refl && !any_overflow, q_refl, &S.gen);
-            else pa_publish(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
+            else pa_publish<PACKED>(ready_n, 0xffffffffu, want_refl && !any_overflow, k_refl, &S.gen);
             if (refr_in_lds) pa_publish(S.ready_lf, PA_LDS_F_PAGES - 1u, want_refr, k_refr, &S.gen);
-            else pa_publish(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
+            else pa_publish<PACKED>(ready_f, ring_page_mask, want_refr, k_refr, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
             /* get_shade up to its first shadow cast (main.rs:407-433) */
             if (want_shade) {
@@ -681,9 +682,9 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
             const bool any_overflow = __builtin_amdgcn_ballot_w64(overflow) != 0ull;
             if (again_in_lds) pa_publish(S.ready_lf, PA_LDS_F_PAGES - 1u, requeue, k_again, &S.gen);
-            else pa_publish(ready_f, ring_page_mask, requeue, k_again, &S.gen);
+            else pa_publish<PACKED>(ready_f, ring_page_mask, requeue, k_again, &S.gen);
             if (child_in_lds) pa_publish(S.ready_ln, PA_LDS_N_PAGES - 1u, escape && !any_overflow, q_child, &S.gen);
-            else pa_publish(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
+            else pa_publish<PACKED>(ready_n, 0xffffffffu, escape && !any_overflow, k_child, &S.gen);
             if (any_overflow && lane == 0u) { S.abort = 1u; atomicExch(pp.global + PW_G_OVERFLOW, 1u); }
             /* the decay (a powf in binary64) is only read by the fold: after the child is on its way */
             if (escape && !overflow) {
@@ -908,10 +909,17 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     }
 }
 
+static size_t pwf_dynamic_lds(uint32_t node_cap, uint32_t ring_cap) {
+    const bool packed = pa_ready_packed(node_cap, ring_cap);
+    return (size_t)(PA_READY_WORDS((node_cap + 63u) / 64u, packed) + 2u * PA_READY_WORDS(ring_cap / 64u, packed)) * sizeof(uint32_t);
+}
+
 int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap) {
     int n = 0;
-    const size_t lds = (size_t)((node_cap + 63u) / 64u + 2u * (ring_cap / 64u)) * sizeof(uint32_t);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel, (int)PA_THREADS, lds) != hipSuccess || n < 1) n = 1;
+    const size_t lds = pwf_dynamic_lds(node_cap, ring_cap);
+    const hipError_t e = pa_ready_packed(node_cap, ring_cap) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<true>, (int)PA_THREADS, lds)
+                                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<false>, (int)PA_THREADS, lds);
+    if (e != hipSuccess || n < 1) n = 1;
     return n;
 }
 
@@ -953,8 +961,9 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const P
 #endif
     if (init) hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     if (first_band) record_main_kernel_event(0, stream); /* the pair brackets all bands of a call (one, up to ~8 Mpixel) */
-    const size_t lds = (size_t)((pp.node_cap + 63u) / 64u + 2u * (pp.ring_cap / 64u)) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pwf_kernel, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    const size_t lds = pwf_dynamic_lds(pp.node_cap, pp.ring_cap);
+    if (pa_ready_packed(pp.node_cap, pp.ring_cap)) hipLaunchKernelGGL(pwf_kernel<true>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    else hipLaunchKernelGGL(pwf_kernel<false>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
     if (last_band) record_main_kernel_event(1, stream);
     return hipGetLastError();
 }

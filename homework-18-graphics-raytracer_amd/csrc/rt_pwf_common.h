@@ -52,6 +52,18 @@ __device__ __forceinline__ void pw_slot_to_pixel(const KernelFrame &fr, uint32_t
  * fuller is to be had — SEALED: `alloc` is moved to the page boundary by compare-and-swap so that no reservation can slip
  * in, and the page is taken with the items it has.  All bookkeeping is in LDS; see the header of rt_pwf.hip. */
 #define PA_SEALED 0x80000000u
+/* ready[]: one entry per page (its item count, <= 64, and a sealed flag): a word each, or — PACKED — 16 bits each, two to a
+ * word.  LDS is what limits the number of resident workgroups, and a frame of several megapixels has thousands of pages
+ * (12 KB of words at 8 Mpixel: one workgroup per CU less); below that the word form is used, which is the faster one (the
+ * claims run on one lane, every instruction of theirs at a wave's price).  pa_ready_packed is the rule kernel and launcher
+ * share. */
+#define PA_SEALED16 0x8000u
+#define PA_READY_WORDS(pages, packed) ((packed) ? ((pages) + 1u) / 2u : (pages))
+#define PA_READY_UNPACKED_LIMIT 8192u /* bytes: with the kernel's 45 KB of item pages, what leaves room for three workgroups per CU */
+__host__ __device__ __forceinline__ bool pa_ready_packed(uint32_t node_cap, uint32_t ring_cap) {
+    return ((node_cap + 63u) / 64u + 2u * (ring_cap / 64u)) * 4u > PA_READY_UNPACKED_LIMIT;
+}
+__device__ __forceinline__ uint32_t pa_ready_shift(uint32_t idx) { return (idx & 1u) << 4; }
 struct PaQueue {
     uint32_t alloc; /* next position to reserve */
     uint32_t taken; /* next PAGE to claim */
@@ -69,7 +81,29 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_a
 
 /* lane 0 only.  Try to claim the next page of a queue; on success *start is its first position and the return value its
  * item count.  ready[] holds one word per page (index masked for the rings). */
+template <bool PACKED = false>
 __device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
+    if (PACKED) {
+        for (int tries = 0; tries < 4; ++tries) {
+            const uint32_t page = lds_load(&q->taken);
+            const uint32_t a = lds_load(&q->alloc);
+            if (a <= page * 64u) return 0u; /* empty */
+            const uint32_t idx = page & page_mask, sh = pa_ready_shift(idx);
+            const uint32_t w = (lds_load(&ready[idx >> 1]) >> sh) & 0xffffu;
+            const uint32_t c = w & 0x7fffu;
+            if (c == 64u || (w & PA_SEALED16) != 0u) {
+                if (atomicCAS(&q->taken, page, page + 1u) == page) {
+                    atomicAnd(&ready[idx >> 1], ~(0xffffu << sh));
+                    *start = page * 64u;
+                    return c;
+                }
+                continue;
+            }
+            if (min_partial == 0u || a >= (page + 1u) * 64u || c < min_partial || c != a - page * 64u) return 0u;
+            if (atomicCAS(&q->alloc, a, (page + 1u) * 64u) == a) atomicOr(&ready[idx >> 1], PA_SEALED16 << sh);
+        }
+        return 0u;
+    }
     for (int tries = 0; tries < 4; ++tries) {
         const uint32_t page = lds_load(&q->taken);
         const uint32_t a = lds_load(&q->alloc);
@@ -113,6 +147,7 @@ __device__ __forceinline__ uint32_t pa_try_append(PaQueue *q, const uint32_t *re
 }
 
 /* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
+template <bool PACKED = false>
 __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
     if (mask == 0ull) return;
@@ -122,7 +157,12 @@ __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, 
     const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)pos, leader); /* the leader holds the lowest position */
     if ((int)(threadIdx.x & 63u) == leader) {
         const uint32_t p0 = first >> 6, p1 = (first + n - 1u) >> 6;
-        if (p0 == p1) {
+        if (PACKED) {
+            const uint32_t i0 = p0 & page_mask, i1 = p1 & page_mask;
+            const uint32_t n0 = p0 == p1 ? n : (p1 << 6) - first;
+            atomicAdd(&ready[i0 >> 1], n0 << pa_ready_shift(i0));
+            if (p0 != p1) atomicAdd(&ready[i1 >> 1], (n - n0) << pa_ready_shift(i1));
+        } else if (p0 == p1) {
             atomicAdd(&ready[p0 & page_mask], n);
         } else {
             const uint32_t n0 = (p1 << 6) - first;
