@@ -321,3 +321,14 @@ def test_captured_call_replays_between_direct_calls(ref):
             w, c = (wb, cb) if step != 3 else (wa, ca)
             assert _mismatches(got.cpu().numpy(), w) == 0, f"direct call at step {step}"
             assert int(count.item()) == c
+
+
+def test_frame_large_enough_for_packed_page_counters(ref):
+    """Beyond ~4 Mpixel the arena queues' page counters are packed two to a word so that three workgroups per CU still fit
+    in LDS (rt_pwf_common.h pa_ready_packed: the kernel's second instantiation): 3840x2160 against the oracle."""
+    world, cam, scene = ref
+    frame = rt.Frame.full(3840, 2160, 3)
+    got, casts = rt.render_whitted_numpy(scene, cam, frame)
+    want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
+    assert _mismatches(got, want) == 0
+    assert casts == wcasts
