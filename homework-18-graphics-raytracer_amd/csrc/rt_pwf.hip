@@ -15,7 +15,7 @@
  * A workgroup (eight waves) owns an arena in HBM with its node records and three queues, and keeps the head of each queue
  * in LDS: a few pages of SHADE, REFR and NODE items (PA_LDS_*_PAGES; 44 KB per workgroup, three workgroups per CU) that
  * producers fill while there is room and consumers empty first — the arena's rings take only what does not fit, which on
- * the reference frame is little: 1.0 GB of HBM traffic per 1080p frame instead of 2.5 GB, 1.20 ms instead of 1.28
+ * the reference frame is little: 0.85 GB of HBM traffic per 1080p frame instead of 2.5 GB, 1.20 ms instead of 1.28
  * (profiles/README.md, round 2).  A page's slot is written again only after its consumer has the items in registers
  * (pa_release_page: pages are released in the order they were claimed).  All 64 lanes of a chunk are
  * in the same phase, so the code between casts runs once; an item is a few dozen bytes, so nothing but the cast's own
@@ -55,6 +55,8 @@
  * (plus the successor a wave is writing while the item is still being read), and the rings hold node_cap + 1024 items.
  * Arenas have a fixed capacity: a workgroup stops taking tiles when its arena fills up, and if a frame cannot be
  * finished that way an overflow flag makes the launcher's trailing per-pixel kernel (a no-op otherwise) render it.
+ * The last workgroup to leave (a count of workgroups done) decides that, publishes the cast count and zeroes the block of
+ * global words the next launch on the workspace will use: a frame is one launch (rt_kernels.h PwParams, rt_api.hip).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
