@@ -327,3 +327,27 @@ def test_argument_validation(ctx):
     acc = torch.zeros((16, 16, 3), dtype=torch.float32, device="cuda")
     with pytest.raises(rt.RtError):
         rt.render_distributed(scene, camera, other, rng, 1, accum=acc)  # RNG built for a different tile
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 5])
+def test_other_numbers_of_lights(n_lights):
+    """The stochastic pass with none, one and five lights (the shade kernel keys its request lists on the first three)."""
+    import torch
+    import _scenes
+
+    world, cam = _scenes.random_world(50 + n_lights, 30, 3, n_lights=n_lights), _scenes.camera(5)
+    scene = rt.Scene(world)
+    frame = rt.Frame.full(64, 48, 5)
+    rng = rt.Rng(frame)
+    samples = torch.empty((3, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    valid = torch.empty((3, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, cam, frame, rng, 3, focus=3.0, blur=0.04, samples=samples, valid=valid, ray_count=cnt)
+    torch.cuda.synchronize()
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), cam, frame, st, 3, focus=3.0, blur=0.04)
+    s = samples.cpu().numpy()
+    same = (s.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(s) & np.isnan(ws))
+    assert same.all(), f"{(~same).sum()} channels differ"
+    assert np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
+    assert np.array_equal(rng.download(), st)

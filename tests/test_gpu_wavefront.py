@@ -332,3 +332,13 @@ def test_frame_large_enough_for_packed_page_counters(ref):
     want, wcasts = _oracle.render_whitted(world.desc(), cam, frame)
     assert _mismatches(got, want) == 0
     assert casts == wcasts
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 2, 4, 5, 9])
+@pytest.mark.parametrize("variant", PATHS + [2])
+def test_other_numbers_of_lights(n_lights, variant):
+    """get_shade's loop (main.rs:413-461) over none, fewer and more lights than the reference scene's three — the search
+    for an item's next light runs with the wave in step, and a build with SHADE queues by light (PA_LQ) files lights beyond
+    its queues together — on the wavefront path and the per-pixel kernel."""
+    world = _scenes.random_world(40 + n_lights, 30, 3, n_lights=n_lights)
+    _check(world, _scenes.camera(7), rt.Frame.full(120, 80, 5), budget=16, variant=variant)
