@@ -206,6 +206,35 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
  * not (nearly) parallel to any of the cluster's face planes — so each of its triangles would compute a finite t, a
  * finite plane point outside its own bounding circle, and reject it on a negative signed area.  Comparisons are written
  * so that NaN anywhere means "cannot skip". */
+#ifdef RT_DIAG_NEED /* diagnostic build: how many of the triangle tests a wave runs its lanes actually need (tools/diag_need.py) */
+static __device__ unsigned long long g_need_totals[4]; /* wave-casts | triangles visited | lane-tests run (active lanes x visited) | lane-tests needed */
+#define RT_DIAG_NEED_READER(name)                                                                               \
+    extern "C" int name(unsigned long long *out4, int reset) {                                                  \
+        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rt::g_need_totals), 4 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_need_totals), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }
+/* cluster_skippable's condition for ONE lane: this lane's ray gets no accepted hit from the node */
+__device__ __forceinline__ bool cluster_skippable_lane(const DevSegment &g, const Ray &ray, const CastMasks &m) {
+    if (g.n_normals == 0u) return false;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (((m.filter_ok >> lane) & 1ull) == 0ull) return false;
+    const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - ray.o;
+    const V3 cr = cross(disp, ray.d);
+    const float dd = dot(ray.d, ray.d);
+    if (!(dot(cr, cr) > g.r2_hi * dd)) return false;
+    bool steep = true;
+    if (g.n_normals == RT_SEGMENT_CONE) {
+        const float ad = dot(v3(g.normals[0][0], g.normals[0][1], g.normals[0][2]), ray.d);
+        steep = ad * ad >= g.normals[0][3] * dd;
+    } else {
+        for (uint32_t k = 0; k < g.n_normals; ++k)
+            steep = steep && rtdm::f_abs(dot(v3(g.normals[k][0], g.normals[k][1], g.normals[k][2]), ray.d)) >= 1.0e-3f;
+    }
+    return steep;
+}
+#endif
+
 __device__ __forceinline__ bool cluster_skippable(const DevSegment &g, const Ray &ray, const CastMasks &m) {
     const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - ray.o;
     const V3 cr = cross(disp, ray.d);
@@ -293,6 +322,12 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
      * neighbouring leaves that are visited go through the loop in one call (its set-up and first fetches are paid once). */
     uint32_t run_first = 0u, run_count = 0u;
     const uint32_t n_nodes = sc.n_segments;
+#ifdef RT_DIAG_NEED
+    {
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u) atomicAdd(&g_need_totals[0], 1ull);
+    }
+#endif
     for (uint32_t k = 0; k < n_nodes;) {
         const DevSegment &g = sc.segments[k];
         if (g.n_normals != 0u && cluster_skippable(g, ray, m)) {
@@ -303,6 +338,16 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
         }
         k += 1u;
         if (g.count == 0u) continue; /* an inner node somebody may hit: on to its children */
+#ifdef RT_DIAG_NEED
+        {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true), need = __builtin_amdgcn_ballot_w64(!cluster_skippable_lane(g, ray, m));
+            if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u) {
+                atomicAdd(&g_need_totals[1], (unsigned long long)g.count);
+                atomicAdd(&g_need_totals[2], (unsigned long long)g.count * (unsigned long long)__builtin_popcountll(act));
+                atomicAdd(&g_need_totals[3], (unsigned long long)g.count * (unsigned long long)__builtin_popcountll(need));
+            }
+        }
+#endif
         if (run_count == 0u) run_first = g.first;
         run_count += g.count; /* leaves are contiguous in triangle order unless something was skipped in between (then the run was closed) */
     }

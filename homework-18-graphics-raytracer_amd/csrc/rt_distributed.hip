@@ -1492,3 +1492,6 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
 }
 
 } /* namespace rt */
+#ifdef RT_DIAG_NEED
+RT_DIAG_NEED_READER(rt_diag_read_need_dist)
+#endif

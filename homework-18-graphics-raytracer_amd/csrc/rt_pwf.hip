@@ -975,3 +975,6 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const P
 #ifdef RT_DIAG_STAGES
 RT_DIAG_STAGE_READER(rt_diag_read_stages_pwf)
 #endif
+#ifdef RT_DIAG_NEED
+RT_DIAG_NEED_READER(rt_diag_read_need_pwf)
+#endif
