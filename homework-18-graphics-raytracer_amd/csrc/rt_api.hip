@@ -207,9 +207,18 @@ uint64_t rt_frame_pixels(const rt_frame *f) {
     return (uint64_t)rt_frame_rows(f) * (uint64_t)(f->x1 - f->x0);
 }
 
-int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
-    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
-    *out_scene = nullptr;
+/* Everything rt_scene_create derives from the ABI arrays, on the host (no HIP call in here): the device records of
+ * rt_device_scene.h.  Also behind rt_scene_describe_nodes, which lets a test look at the node array without a GPU. */
+struct SceneLayout {
+    std::vector<rt::DevTri> tris;
+    std::vector<rt::DevTriAttr> attrs;
+    std::vector<rt::DevSegment> segments;
+    std::vector<rt::DevTriHead> heads;
+    std::vector<rt::DevSphere> spheres;
+    double scene_extent = 0.0;
+};
+
+static int layout_scene(const rt_scene_desc *desc, SceneLayout &layout) {
     if ((desc->n_triangles && !desc->triangles) || (desc->n_spheres && !desc->spheres) || (desc->n_materials && !desc->materials) ||
         (desc->n_lights && !desc->lights))
         return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null array with non-zero count");
@@ -230,8 +239,10 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: unknown material function");
 
     using rt::V3;
-    std::vector<rt::DevTri> tris(desc->n_triangles);
-    std::vector<rt::DevTriAttr> attrs(desc->n_triangles);
+    std::vector<rt::DevTri> &tris = layout.tris;
+    std::vector<rt::DevTriAttr> &attrs = layout.attrs;
+    tris.assign(desc->n_triangles, rt::DevTri());
+    attrs.assign(desc->n_triangles, rt::DevTriAttr());
     for (uint32_t i = 0; i < desc->n_triangles; ++i) {
         const rt_triangle &s = desc->triangles[i];
         rt::DevTri &t = tris[i];
@@ -262,7 +273,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         a.uv2x = s.vertices[2].uv[0]; a.uv2y = s.vertices[2].uv[1];
     }
     /* bounding spheres for the conservative rejection in the intersection loop (rt_device_scene.h) */
-    double scene_extent = 0.0;
+    double &scene_extent = layout.scene_extent;
+    scene_extent = 0.0;
     for (uint32_t i = 0; i < desc->n_triangles; ++i)
         for (int v = 0; v < 3; ++v)
             for (int k = 0; k < 3; ++k) {
@@ -331,14 +343,19 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
      * every node that is small against the scene gets a bounding sphere and either up to 8 representative face normals or a
      * normal cone, and can then be skipped by a wave none of whose rays can hit anything in it.  Everything else is a plain
      * leaf that is always visited. */
-    std::vector<rt::DevSegment> segments;
+    std::vector<rt::DevSegment> &segments = layout.segments;
+    segments.clear();
     {
         const bool clusters_off = filter_off || getenv("RT_AMD_NO_CLUSTERS") != nullptr; /* A/B switch; results are the same either way */
         const bool flat_only = getenv("RT_AMD_NO_HIERARCHY") != nullptr; /* A/B: one cluster per object run, explicit normals only (round 1) */
         uint32_t single_leaf_max = 64u; /* A/B: objects up to this many triangles stay one leaf */
         if (const char *v = getenv("RT_AMD_SINGLE_LEAF_MAX")) { if (*v) single_leaf_max = (uint32_t)atoi(v); }
+        /* A plain run may only grow the leaf before it if that leaf is not inside a subtree that is already closed: an inner
+         * node's skip_to jumps over everything emitted below it, so triangles appended to a leaf in there would be skipped with
+         * it.  merge_barrier = the number of nodes no later run may be merged into (moved whenever a subtree or a tree ends). */
+        size_t merge_barrier = 0;
         auto push_plain = [&](uint32_t first, uint32_t count) {
-            if (!segments.empty() && segments.back().n_normals == 0u && segments.back().count != 0u &&
+            if (segments.size() > merge_barrier && segments.back().n_normals == 0u && segments.back().count != 0u &&
                 segments.back().first + segments.back().count == first) {
                 segments.back().count += count; /* adjacent plain runs are one leaf */
                 return;
@@ -429,7 +446,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         struct Emit {
             static void go(uint32_t l0, uint32_t l1, uint32_t run_lo, uint32_t run_hi, std::vector<rt::DevSegment> &out,
                            const std::function<bool(uint32_t, uint32_t, rt::DevSegment *)> &stats,
-                           const std::function<void(uint32_t, uint32_t)> &plain) {
+                           const std::function<void(uint32_t, uint32_t)> &plain, size_t *barrier) {
                 const uint32_t t0 = run_lo + l0 * RT_LEAF_TRIANGLES;
                 const uint32_t t1 = std::min<uint64_t>(run_hi, (uint64_t)run_lo + (uint64_t)l1 * RT_LEAF_TRIANGLES);
                 rt::DevSegment g;
@@ -452,8 +469,11 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
                 }
                 uint32_t child = 1u; /* leaves per child: the largest power of 16 below the span */
                 while ((uint64_t)child * 16u < (uint64_t)(l1 - l0)) child *= 16u;
-                for (uint32_t c0 = l0; c0 < l1; c0 += child) go(c0, std::min(l1, c0 + child), run_lo, run_hi, out, stats, plain);
-                if (at != (size_t)-1) out[at].skip_to = (uint32_t)out.size();
+                for (uint32_t c0 = l0; c0 < l1; c0 += child) go(c0, std::min(l1, c0 + child), run_lo, run_hi, out, stats, plain, barrier);
+                if (at != (size_t)-1) {
+                    out[at].skip_to = (uint32_t)out.size();
+                    *barrier = out.size(); /* the subtree is closed: nothing may be appended to a leaf inside it */
+                }
             }
         };
         for (uint32_t i = 0; i < desc->n_triangles;) {
@@ -470,12 +490,31 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
                 memset(&g, 0, sizeof g);
                 if (node_stats(i, j, &g)) { g.first = i; g.count = j - i; g.skip_to = (uint32_t)segments.size() + 1u; segments.push_back(g); }
                 else if (flat_only) push_plain(i, j - i);
-                else Emit::go(0u, (j - i + RT_LEAF_TRIANGLES - 1u) / RT_LEAF_TRIANGLES, i, j, segments, node_stats, push_plain);
+                else Emit::go(0u, (j - i + RT_LEAF_TRIANGLES - 1u) / RT_LEAF_TRIANGLES, i, j, segments, node_stats, push_plain, &merge_barrier);
             } else {
                 const uint32_t n_leaves = (j - i + RT_LEAF_TRIANGLES - 1u) / RT_LEAF_TRIANGLES;
-                Emit::go(0u, n_leaves, i, j, segments, node_stats, push_plain);
+                Emit::go(0u, n_leaves, i, j, segments, node_stats, push_plain, &merge_barrier);
             }
             i = j;
+        }
+        /* clustered leaves: how their triangles are dealt to the lanes of a pair-wise pass (rt_device_scene.h RT_SEG_PAIR_*) */
+        const bool pairs_off = getenv("RT_AMD_NO_PAIRS") != nullptr; /* A/B switch; results are the same either way */
+        for (rt::DevSegment &g : segments) {
+            if (g.count == 0u || g.n_normals == 0u || pairs_off || g.count > 64u) continue;
+            uint32_t best_k = 0u, best_ck = 0u, best_r = 0u;
+            double best_fill = 0.0;
+            for (uint32_t K = 1u; K <= 8u; ++K) {
+                const uint32_t ck = (g.count + K - 1u) / K;
+                if (ck < 4u && K > 1u) break;
+                const uint32_t R = 64u / ck;
+                const double fill = (double)R * g.count / K; /* pairs per full pass */
+                if (fill > best_fill * 1.05) { best_fill = fill; best_k = K; best_ck = ck; best_r = R; }
+            }
+            if (best_k == 0u) continue;
+            auto put = [](float *slot, uint32_t v) { memcpy(slot, &v, sizeof v); };
+            put(&g.normals[1][3], best_ck | (best_k << 8) | (best_r << 16));
+            put(&g.normals[2][3], 65535u / best_ck + 1u);
+            put(&g.normals[3][3], 65535u / best_k + 1u);
         }
     }
     /* triangles on their predecessor's plane (rt_device_scene.h RT_TRI_FOLLOWS): same segment; n and d equal bit for bit, or
@@ -500,7 +539,16 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
             }
         }
     }
-    std::vector<rt::DevSphere> spheres(desc->n_spheres);
+    std::vector<rt::DevTriHead> &heads = layout.heads;
+    heads.assign(desc->n_triangles, rt::DevTriHead());
+    for (uint32_t i = 0; i < desc->n_triangles; ++i) {
+        rt::DevTriHead &h = heads[i];
+        const rt::DevTri &t = tris[i];
+        h.n[0] = t.n[0]; h.n[1] = t.n[1]; h.n[2] = t.n[2]; h.d = t.d;
+        h.bc[0] = t.bcx; h.bc[1] = t.bcy; h.bc[2] = t.bcz; h.bq = t.bq;
+    }
+    std::vector<rt::DevSphere> &spheres = layout.spheres;
+    spheres.assign(desc->n_spheres, rt::DevSphere());
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const rt_sphere &s = desc->spheres[i];
         rt::DevSphere &d = spheres[i];
@@ -510,6 +558,41 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
         d.r2 = s.radius * s.radius; /* radius.powi(2), main.rs:272 */
         d.obj = s.object_index;
     }
+    return RT_OK;
+}
+
+/* Diagnostics: the node array (rt_device_scene.h) rt_scene_create would build for `desc`, six words per node — first, count,
+ * n_normals, skip_to, the pair-wise dealing word, 0 — without touching a device. */
+int rt_scene_describe_nodes(const rt_scene_desc *desc, uint32_t *out_words, uint32_t cap_nodes, uint32_t *n_nodes) {
+    if (!desc || !n_nodes || (cap_nodes && !out_words)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_describe_nodes: null argument");
+    SceneLayout layout;
+    const int rc = layout_scene(desc, layout);
+    if (rc != RT_OK) return rc;
+    *n_nodes = (uint32_t)layout.segments.size();
+    for (uint32_t k = 0; k < *n_nodes && k < cap_nodes; ++k) {
+        const rt::DevSegment &g = layout.segments[k];
+        uint32_t pair_word;
+        memcpy(&pair_word, &g.normals[1][3], sizeof pair_word);
+        uint32_t *o = out_words + (size_t)k * 6u;
+        o[0] = g.first; o[1] = g.count; o[2] = g.n_normals; o[3] = g.skip_to; o[4] = pair_word; o[5] = 0u;
+    }
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out_scene = nullptr;
+    SceneLayout layout;
+    {
+        const int rc = layout_scene(desc, layout);
+        if (rc != RT_OK) return rc;
+    }
+    const std::vector<rt::DevTri> &tris = layout.tris;
+    const std::vector<rt::DevTriAttr> &attrs = layout.attrs;
+    const std::vector<rt::DevSegment> &segments = layout.segments;
+    const std::vector<rt::DevTriHead> &heads = layout.heads;
+    const std::vector<rt::DevSphere> &spheres = layout.spheres;
+    const double scene_extent = layout.scene_extent;
 
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t off_tris = 0;
@@ -518,7 +601,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     const size_t off_mats = off_spheres + up(spheres.size() * sizeof(rt::DevSphere));
     const size_t off_lights = off_mats + up(desc->n_materials * sizeof(rt_material));
     const size_t off_segments = off_lights + up(desc->n_lights * sizeof(rt_light));
-    const size_t total = off_segments + up(segments.size() * sizeof(rt::DevSegment)) + 256;
+    const size_t off_heads = off_segments + up(segments.size() * sizeof(rt::DevSegment));
+    const size_t total = off_heads + up(heads.size() * sizeof(rt::DevTriHead)) + 256;
 
     std::vector<unsigned char> blob(total, 0);
     if (!tris.empty()) memcpy(&blob[off_tris], tris.data(), tris.size() * sizeof(rt::DevTri));
@@ -527,6 +611,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (desc->n_materials) memcpy(&blob[off_mats], desc->materials, desc->n_materials * sizeof(rt_material));
     if (desc->n_lights) memcpy(&blob[off_lights], desc->lights, desc->n_lights * sizeof(rt_light));
     if (!segments.empty()) memcpy(&blob[off_segments], segments.data(), segments.size() * sizeof(rt::DevSegment));
+    if (!heads.empty()) memcpy(&blob[off_heads], heads.data(), heads.size() * sizeof(rt::DevTriHead));
 
     rt_scene *sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -551,6 +636,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.n_lights = desc->n_lights;
     sc->ks.segments = reinterpret_cast<const rt::DevSegment *>(base + off_segments);
     sc->ks.n_segments = (uint32_t)segments.size();
+    sc->ks.heads = reinterpret_cast<const rt::DevTriHead *>(base + off_heads);
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);

@@ -15,6 +15,17 @@
 
 namespace rt {
 
+/* Scene records read with a wave-uniform index (a node of the triangle array, a sphere, a light): through the CONSTANT address
+ * space, so that the compiler fetches them with scalar loads.  Left as ordinary global pointers it cannot — the kernels store to
+ * global memory, and a load that a store might clobber has to be a vector load (global_load + v_readfirstlane, a full memory
+ * round trip each and usually one after the other: the node walk of the chain kernel spent 40 % of the cast there).  The scene is
+ * immutable while a kernel runs (rt_scene_create uploads it once), which is what the address space promises. */
+#define RT_UNIFORM __attribute__((address_space(4)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* a built-in vector: HIP's uint4 class cannot be copied out of another address space */
+template <class T> __device__ __forceinline__ const RT_UNIFORM T &uniform_ref(const T *p) {
+    return *reinterpret_cast<const RT_UNIFORM T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 /* ---- ray / hit records ------------------------------------------------------ */
 
 enum : uint32_t { FACE_FRONT = 0u, FACE_BACK = 1u, FACE_BOTH = 2u }; /* main.rs:52-57 */
@@ -207,15 +218,23 @@ __device__ __forceinline__ void cast_asm_triangles(const DevTri *tris_range, uin
  * finite plane point outside its own bounding circle, and reject it on a negative signed area.  Comparisons are written
  * so that NaN anywhere means "cannot skip". */
 #ifdef RT_DIAG_NEED /* diagnostic build: how many of the triangle tests a wave runs its lanes actually need (tools/diag_need.py) */
-static __device__ unsigned long long g_need_totals[4]; /* wave-casts | triangles visited | lane-tests run (active lanes x visited) | lane-tests needed */
+/* wave-casts | triangles visited | lane-tests run (active lanes x visited wave-uniformly + 64 x pair passes) | lane-tests needed |
+ * [4] clustered leaves tested pair-wise | [5] pair passes | [6] of them with a pair that reached the signed areas | [7] such pairs |
+ * [8] pairs accepted | [9] clustered leaves run wave-uniformly | [10] casts redone for a NaN distance | [11] casts with lanes missing |
+ * [16 + n] clustered leaves that n lanes needed */
+#define RT_DIAG_NEED_WORDS 96
+static __device__ unsigned long long g_need_totals[RT_DIAG_NEED_WORDS];
 #define RT_DIAG_NEED_READER(name)                                                                               \
     extern "C" int name(unsigned long long *out4, int reset) {                                                  \
-        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rt::g_need_totals), 4 * sizeof(unsigned long long)) != hipSuccess) return -1; \
-        if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_need_totals), z, sizeof z) != hipSuccess) return -1; } \
+        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rt::g_need_totals), RT_DIAG_NEED_WORDS * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[RT_DIAG_NEED_WORDS] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_need_totals), z, sizeof z) != hipSuccess) return -1; } \
         return 0;                                                                                               \
     }
+#endif
+
 /* cluster_skippable's condition for ONE lane: this lane's ray gets no accepted hit from the node */
-__device__ __forceinline__ bool cluster_skippable_lane(const DevSegment &g, const Ray &ray, const CastMasks &m) {
+template <class Segment>
+__device__ __forceinline__ bool cluster_skippable_lane(const Segment &g, const Ray &ray, const CastMasks &m) {
     if (g.n_normals == 0u) return false;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (((m.filter_ok >> lane) & 1ull) == 0ull) return false;
@@ -233,9 +252,9 @@ __device__ __forceinline__ bool cluster_skippable_lane(const DevSegment &g, cons
     }
     return steep;
 }
-#endif
 
-__device__ __forceinline__ bool cluster_skippable(const DevSegment &g, const Ray &ray, const CastMasks &m) {
+template <class Segment>
+__device__ __forceinline__ bool cluster_skippable(const Segment &g, const Ray &ray, const CastMasks &m) {
     const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - ray.o;
     const V3 cr = cross(disp, ray.d);
     const float dd = dot(ray.d, ray.d);
@@ -284,7 +303,7 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
     }
     const uint32_t ns = sc.n_spheres;
     for (uint32_t i = 0; i < ns; ++i) { /* main.rs:264-324 */
-        const DevSphere &S = sc.spheres[i];
+        const auto &S = uniform_ref(sc.spheres + i);
         const V3 c = v3(S.c[0], S.c[1], S.c[2]);
         const V3 disp = c - ray.o;
         const float lsd = magnitude(cross(disp, ray.d));
@@ -329,7 +348,7 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
     }
 #endif
     for (uint32_t k = 0; k < n_nodes;) {
-        const DevSegment &g = sc.segments[k];
+        const auto &g = uniform_ref(sc.segments + k);
         if (g.n_normals != 0u && cluster_skippable(g, ray, m)) {
             if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
             run_count = 0u;
@@ -353,6 +372,315 @@ __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray 
     }
     if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
     return cast_finish(sc, ray, best.t, best.prim, &best);
+}
+
+/* ---- World::cast with the sparsely needed clusters tested PAIR-WISE ------------------------------------------------------
+ * cast_asm runs a clustered leaf for the whole wave as soon as ONE lane's ray may hit it: a wave of 64 unrelated rays (the
+ * scattered rays of the stochastic pass, shadow rays of scattered hit points) visits 56 of the reference scene's 64 triangles
+ * per cast while a lane's own ray needs 15 of them (profiles/r02_lane_tests_needed.txt).  Here the few rays that need a leaf
+ * pay for it: the leaf's (ray, triangle) pairs are dealt to the 64 lanes — lane l holds triangle l % ck of the (l / ck)-th
+ * (ray, chunk) sub-job of the pass (rt_device_scene.h RT_SEG_PAIR_*) — the ray comes over from its owner's lane
+ * (ds_bpermute), the triangle's plane and bounding sphere from DevTriHead (two 16-byte loads per lane), and the lane runs the
+ * reference's single-triangle test (main.rs:184-224) in the reference's operation order: culling, exclusion, t, `t <= 0`,
+ * the conservative bounding-sphere rejection of rt_cast_asm.h, and — for the few pairs that get that far — the three signed
+ * areas.  What is left of main.rs:229-233, the sequential nearest rule "replace unless nearest_t < t", picks among all the
+ * candidates of a cast the one with the smallest t and, among equal t, the LAST index — as long as no candidate's t is NaN
+ * (t <= 0 is gone, so every t is a positive float or +inf and orders like its bits).  So each accepted pair does one
+ * ds_min_u64 of (bits(t) << 32 | ~index) on its ray's slot, the wave-uniform loop covers the leaves that many lanes need
+ * (same rule, its own running minimum), and the owner takes the smaller key of the two.  A NaN t anywhere — the one case
+ * where "sequential" and "minimum" part ways (main.rs:205 lets NaN through, and `nearest_t < NaN` is false) — sends the whole
+ * wave through cast_asm instead: rare, and exact without an argument.  The winner's n.d and signed areas (finish_hit's
+ * barycentrics) are re-evaluated by its owner: the same operations on the same values.
+ *
+ * All 64 lanes must be executing (the callers sit in wave-uniform control flow and pass `active`); if some are not, the
+ * wave takes cast_asm.  One PairLds per wave. */
+#ifndef RT_PAIR_CANDIDATES
+#define RT_PAIR_CANDIDATES 128u /* >= 128: a pass may add 64 and the list is drained when it holds more than 64 */
+#endif
+struct PairLds {
+    unsigned long long key[64]; /* per ray (owner lane): the smallest (bits(t) << 32 | ~triangle) accepted pair-wise */
+    uint32_t rank_lane[64];     /* the current leaf's needing lanes, in lane order */
+    uint2 cand[RT_PAIR_CANDIDATES]; /* pairs that got as far as the signed areas: bits(t), owner lane | triangle << 6 */
+    float4 heads[64][2];        /* the current leaf's DevTriHead records (a leaf tested pair-wise has 64 triangles at most) */
+};
+#ifndef RT_PAIR_MAX_NEED
+#define RT_PAIR_MAX_NEED 24u /* a clustered leaf that more lanes than this need is run wave-uniformly */
+#endif
+
+__device__ __forceinline__ float pair_fetch(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+__device__ __forceinline__ void pair_sync() { /* LDS written by some lanes of the wave, read by others */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* The signed areas (main.rs:218-224) for the first `count` entries of the candidate list, one per lane; a pair that passes
+ * puts its key on its ray's slot.  Returns whether a NaN distance was accepted. */
+__device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray, PairLds *pl, const uint32_t lane, const uint32_t count) {
+    const bool mine = lane < count;
+    const uint2 c = pl->cand[lane];
+    const uint32_t owner = c.y & 63u, tri = mine ? c.y >> 6 : 0u;
+    const int from = (int)(owner << 2);
+    const V3 o = v3(pair_fetch(from, ray.o.x), pair_fetch(from, ray.o.y), pair_fetch(from, ray.o.z));
+    const V3 d = v3(pair_fetch(from, ray.d.x), pair_fetch(from, ray.d.y), pair_fetch(from, ray.d.z));
+    bool nan_seen = false;
+    if (mine) {
+        const DevTri &T = sc.tris[tri];
+        const float t = __uint_as_float(c.x);
+        const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+        const V3 p = o + d * t; /* main.rs:210 */
+        const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
+        const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
+        const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
+        if (!(a0 < 0.0f || a1 < 0.0f || a2 < 0.0f)) { /* NaN areas pass (main.rs:224) */
+            nan_seen = t != t;
+            const unsigned long long key = ((unsigned long long)c.x << 32) | (unsigned long long)(0xffffffffu - tri);
+            __hip_atomic_fetch_min(&pl->key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef RT_DIAG_NEED
+            atomicAdd(&g_need_totals[8], 1ull);
+#endif
+        }
+    }
+    return nan_seen;
+}
+
+#ifdef RT_DIAG_PAIR_TIME
+static __device__ unsigned long long g_pair_time[16];
+#define RT_DIAG_PAIR_TIME_READER(name)                                                                          \
+    extern "C" int name(unsigned long long *out16, int reset) {                                                 \
+        if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_pair_time), 16 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pair_time), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }
+#define RT_PAIR_TIME_ARG , unsigned long long *dt
+#else
+#define RT_PAIR_TIME_ARG
+#endif
+__device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ray &ray, const bool active, PairLds *pl RT_PAIR_TIME_ARG) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const CastMasks m = cast_masks(ray, sc.filter_origin2);
+    /* the ray's lane predicates as bits, to travel with it: excluded triangle (or none) | keep_back keep_front ex_if_back ex_if_front filter_ok */
+    const bool ex_some = (ray.excl >> 31) != 0u;
+    const uint32_t ex_face = (ray.excl >> 29) & 3u;
+    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
+    const uint32_t ray_bits = ((ex_some && ex_prim < sc.n_triangles) ? ex_prim : 0x07ffffffu) | (ray.mode != FACE_FRONT ? 1u << 27 : 0u) |
+                              (ray.mode != FACE_BACK ? 1u << 28 : 0u) | ((ex_some && ex_face != FACE_FRONT) ? 1u << 29 : 0u) |
+                              ((ex_some && ex_face != FACE_BACK) ? 1u << 30 : 0u) | ((uint32_t)((m.filter_ok >> lane) & 1ull) << 31);
+    const uint32_t n_nodes = sc.n_segments;
+    /* every leaf wave-uniformly — what cast_asm does — when some lanes of the wave are not here to help, and, the second time
+     * round, when the first found a NaN distance */
+    bool dense_only = __builtin_amdgcn_ballot_w64(true) != ~0ull;
+#ifdef RT_DIAG_NEED
+    if (dense_only && lane == 0u) atomicAdd(&g_need_totals[11], 1ull);
+#endif
+#ifdef RT_DIAG_PAIR_TIME
+    /* wave time by part: dt[1] classify nodes, [2] wave-uniform runs, [3] leaf set-up, [4] passes, [5] signed areas, [6] finish; [7] the cast */
+    unsigned long long tick = __builtin_readcyclecounter();
+    const unsigned long long tick0 = tick;
+#define RT_PAIR_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); dt[k] += now_ - tick; tick = now_; }
+#else
+#define RT_PAIR_TICK(k)
+#endif
+    TriBest best;
+    bool from_pairs;
+    for (;;) {
+        best.t = rtdm::quiet_nan();
+        best.prim = -1;
+        best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
+        from_pairs = false;
+        if (!dense_only) pl->key[lane] = ~0ull;
+        bool nan_seen = false;
+        uint32_t n_cand = 0u; /* wave-uniform */
+        uint32_t run_first = 0u, run_count = 0u;
+#ifdef RT_DIAG_NEED
+        if (lane == 0u) atomicAdd(&g_need_totals[0], 1ull);
+#endif
+        for (uint32_t k = 0;;) {
+            /* what to do with node k: 0 skip it and its subtree, 1 descend, 2 its triangles wave-uniformly, 3 pair-wise, 4 no node left */
+            uint32_t what = 4u, g_first = 0u, g_count = 0u, n_need = 0u, pair_word = 0u, pair_mck = 0u, pair_mk = 0u, next_k = k;
+            bool need = false;
+            unsigned long long needing = 0ull;
+            if (k < n_nodes) {
+                /* the node's record in one round trip: its head and all eight normal slots (scalar loads, issued together; read
+                 * field by field the compiler fetches each where it is first needed, one round trip after the other) */
+                const RT_UNIFORM u32x4 *gp = reinterpret_cast<const RT_UNIFORM u32x4 *>(reinterpret_cast<uintptr_t>(sc.segments + k));
+                const u32x4 h0 = gp[0], h1 = gp[1];
+                float4 nrm[RT_SEGMENT_NORMALS];
+#pragma unroll
+                for (uint32_t q = 0; q < RT_SEGMENT_NORMALS; ++q) {
+                    const u32x4 w = gp[2u + q];
+                    nrm[q] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+                }
+                g_first = h0.x;
+                g_count = h0.y;
+                const uint32_t n_normals = h0.z;
+                pair_word = __float_as_uint(nrm[1].w);
+                pair_mck = __float_as_uint(nrm[2].w);
+                pair_mk = __float_as_uint(nrm[3].w);
+                need = active;
+                if (n_normals != 0u) { /* cluster_skippable_lane, without a branch per normal */
+                    const V3 disp = v3(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z)) - ray.o;
+                    const V3 cr = cross(disp, ray.d);
+                    const float dd = dot(ray.d, ray.d);
+                    const bool miss = ((m.filter_ok >> lane) & 1ull) != 0ull && dot(cr, cr) > __uint_as_float(h0.w) * dd;
+                    const bool cone = n_normals == RT_SEGMENT_CONE;
+                    const float ad = dot(v3(nrm[0].x, nrm[0].y, nrm[0].z), ray.d);
+                    bool steep = cone ? ad * ad >= nrm[0].w * dd : rtdm::f_abs(ad) >= 1.0e-3f;
+#pragma unroll
+                    for (uint32_t q = 1; q < RT_SEGMENT_NORMALS; ++q)
+                        steep = steep & ((rtdm::f_abs(dot(v3(nrm[q].x, nrm[q].y, nrm[q].z), ray.d)) >= 1.0e-3f) | (cone | (q >= n_normals)));
+                    need = active & !(miss & steep);
+                }
+                needing = __builtin_amdgcn_ballot_w64(need);
+                n_need = (uint32_t)__builtin_popcountll(needing);
+                if (needing == 0ull) { what = 0u; next_k = h1.w; }
+                else if (g_count == 0u) { what = 1u; next_k = k + 1u; }
+                else {
+                    what = (dense_only || n_normals == 0u || pair_word == 0u || n_need > RT_PAIR_MAX_NEED) ? 2u : 3u;
+                    next_k = k + 1u;
+#ifdef RT_DIAG_NEED
+                    const unsigned long long diag_active = __builtin_amdgcn_ballot_w64(active);
+                    if (lane == 0u) {
+                        atomicAdd(&g_need_totals[1], (unsigned long long)g_count);
+                        atomicAdd(&g_need_totals[3], (unsigned long long)g_count * n_need);
+                        if (n_normals != 0u) atomicAdd(&g_need_totals[16u + n_need], 1ull);
+                        if (what == 2u) {
+                            atomicAdd(&g_need_totals[2], (unsigned long long)g_count * (unsigned long long)__builtin_popcountll(diag_active));
+                            if (n_normals != 0u) atomicAdd(&g_need_totals[9], 1ull);
+                        }
+                    }
+#endif
+                }
+            }
+            RT_PAIR_TICK(1)
+            /* the one instance of the wave-uniform loop: the run of leaves gathered so far, when the next thing is not its
+             * continuation */
+            if (run_count != 0u && (what == 0u || what >= 3u || (what == 2u && run_first + run_count != g_first))) {
+                if (active) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
+                run_count = 0u;
+                RT_PAIR_TICK(2)
+            }
+            if (what == 4u) break;
+            k = next_k;
+            if (what == 2u) {
+                if (run_count == 0u) run_first = g_first;
+                run_count += g_count;
+            }
+            if (what != 3u) continue;
+
+            /* pair-wise: the leaf's plane records into LDS (one per lane), the needing lanes in lane order, then the passes */
+            const uint32_t ck = pair_word & 0xffu, K = (pair_word >> 8) & 0xffu, R = pair_word >> 16;
+            const uint32_t mck = pair_mck, mk = pair_mk;
+            {
+                const float4 *h = reinterpret_cast<const float4 *>(sc.heads + g_first + (lane < g_count ? lane : 0u));
+                const float4 ha = h[0], hb = h[1];
+                if (need) pl->rank_lane[__builtin_amdgcn_mbcnt_hi((uint32_t)(needing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needing, 0u))] = lane;
+                pl->heads[lane][0] = ha;
+                pl->heads[lane][1] = hb;
+            }
+            pair_sync();
+            const uint32_t slot = (lane * mck) >> 16, in_chunk = lane - slot * ck;
+            const uint32_t n_sub = n_need * K;
+#ifdef RT_DIAG_NEED
+            if (lane == 0u) {
+                atomicAdd(&g_need_totals[2], (unsigned long long)((n_sub + R - 1u) / R) * 64ull);
+                atomicAdd(&g_need_totals[4], 1ull);
+                atomicAdd(&g_need_totals[5], (unsigned long long)((n_sub + R - 1u) / R));
+            }
+#endif
+            RT_PAIR_TICK(3)
+            for (uint32_t sub0 = 0u; sub0 < n_sub; sub0 += R) {
+                const uint32_t sub = sub0 + slot;
+                const uint32_t rank = (sub * mk) >> 16, chunk = sub - rank * K;
+                const uint32_t local = chunk * ck + in_chunk;
+                const bool pair = slot < R && sub < n_sub && local < g_count;
+                const uint32_t owner = pl->rank_lane[rank & 63u] & 63u;
+                const float4 ha = pl->heads[local & 63u][0], hb = pl->heads[local & 63u][1];
+                const uint32_t tri = g_first + local;
+                const int from = (int)(owner << 2);
+                const V3 o = v3(pair_fetch(from, ray.o.x), pair_fetch(from, ray.o.y), pair_fetch(from, ray.o.z));
+                const V3 d = v3(pair_fetch(from, ray.d.x), pair_fetch(from, ray.d.y), pair_fetch(from, ray.d.z));
+                const uint32_t bits = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)ray_bits);
+                const V3 n = v3(ha.x, ha.y, ha.z);
+                const float nd = dot(n, d);
+                const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
+                /* culling (main.rs:185-188) and exclusion (main.rs:190-200): the ray's flags for this facing — keep (bit 27 / 28), excluded if it
+                 * is the excluded triangle (bit 29 / 30) */
+                const uint32_t facing = bits & (bf ? 0x28000000u : 0x50000000u);
+                const bool keep = (facing & 0x18000000u) != 0u, ex_facing = (facing & 0x60000000u) != 0u, ex_tri = (bits & 0x07ffffffu) == tri;
+                const float t = (ha.w - dot(n, o)) / nd; /* main.rs:203-204 */
+                /* `t <= 0` rejects, NaN passes (main.rs:205).  (main.rs:229-233, "nearest_t < t", is the minimum taken at the end.) */
+                bool go = pair & keep & !(ex_tri & ex_facing) & !(t <= 0.0f);
+                const V3 p = o + d * t;                                     /* main.rs:210 */
+                {   /* the conservative bounding-sphere rejection of the wave-uniform loop (rt_cast_asm.h), same operations */
+                    const V3 w = p - v3(hb.x, hb.y, hb.z);
+                    const float q = (w.x * w.x + w.y * w.y) + w.z * w.z;
+                    if (hb.w < q && 1.0e30f > q && (bits >> 31) != 0u) go = false;
+                }
+                const unsigned long long going = __builtin_amdgcn_ballot_w64(go);
+                if (going == 0ull) continue;
+                /* on to the signed areas — later, together with the other pairs that get this far */
+#ifdef RT_DIAG_NEED
+                if (lane == 0u) {
+                    atomicAdd(&g_need_totals[6], 1ull);
+                    atomicAdd(&g_need_totals[7], (unsigned long long)__builtin_popcountll(going));
+                }
+#endif
+                if (go) pl->cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(going >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)going, 0u))] =
+                    make_uint2(__float_as_uint(t), owner | (tri << 6));
+                n_cand += (uint32_t)__builtin_popcountll(going);
+                if (n_cand > RT_PAIR_CANDIDATES - 64u) { /* room for another pass's worth is gone: the first 64 now */
+                    RT_PAIR_TICK(4)
+                    pair_sync();
+                    nan_seen = pair_areas(sc, ray, pl, lane, 64u) || nan_seen;
+                    const uint2 moved = pl->cand[64u + lane];
+                    pair_sync();
+                    pl->cand[lane] = moved;
+                    n_cand -= 64u;
+                    RT_PAIR_TICK(5)
+                }
+            }
+            RT_PAIR_TICK(4)
+        }
+        if (dense_only) break;
+        pair_sync();
+        RT_PAIR_TICK(1)
+        if (n_cand != 0u) {
+            nan_seen = pair_areas(sc, ray, pl, lane, n_cand) || nan_seen;
+            pair_sync();
+        }
+        RT_PAIR_TICK(5)
+        const unsigned long long key = pl->key[lane];
+        const bool odd = nan_seen || (active && best.prim >= 0 && best.t != best.t);
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) { /* a NaN distance somewhere: the reference's sequential rule, literally */
+#ifdef RT_DIAG_NEED
+            if (lane == 0u) atomicAdd(&g_need_totals[10], 1ull);
+#endif
+            dense_only = true;
+            continue;
+        }
+        if (active && key != ~0ull) {
+            const float kt = __uint_as_float((uint32_t)(key >> 32));
+            const int32_t kp = (int32_t)(0xffffffffu - (uint32_t)key);
+            if (best.prim < 0 || kt < best.t || (kt == best.t && kp > best.prim)) {
+                best.t = kt;
+                best.prim = kp;
+                from_pairs = true;
+            }
+        }
+        break;
+    }
+    CastResult cr;
+    cr.prim = -1;
+    cr.t = 0.0f;
+    cr.bf = 0u;
+    cr.a0 = cr.a1 = cr.a2 = 0.0f;
+    if (active) cr = cast_finish(sc, ray, best.t, best.prim, from_pairs ? nullptr : &best);
+#ifdef RT_DIAG_PAIR_TIME
+    RT_PAIR_TICK(6)
+    dt[7] += tick - tick0;
+#endif
+    return cr;
 }
 
 /* What the state machine keeps of a Hit (main.rs:139-147). */

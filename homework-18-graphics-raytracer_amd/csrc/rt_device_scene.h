@@ -56,6 +56,15 @@ struct alignas(32) DevTri {
 };
 static_assert(sizeof(DevTri) == 128, "DevTri must be 128 bytes");
 
+/* The plane and the bounding sphere of a triangle once more, 32 bytes together: what the PAIR-WISE part of the intersection
+ * loop (rt_cast.h cast_pairs: one (ray, triangle) pair per lane, records fetched per lane) needs to decide that a pair can
+ * go no further — two 16-byte loads instead of five out of DevTri.  Same values, bit for bit. */
+struct alignas(16) DevTriHead {
+    float n[3]; float d;
+    float bc[3]; float bq;
+};
+static_assert(sizeof(DevTriHead) == 32, "DevTriHead must be 32 bytes");
+
 /* per-vertex attributes, only read for the winning primitive of a cast */
 struct alignas(16) DevTriAttr {
     float n0[3]; float uv0x;
@@ -83,6 +92,16 @@ static_assert(sizeof(DevTriAttr) == 64, "DevTriAttr must be 64 bytes");
 #ifndef RT_LEAF_TRIANGLES
 #define RT_LEAF_TRIANGLES 16u
 #endif
+/* How a clustered leaf's triangles are dealt to the 64 lanes when only a few rays of a wave need it (cast_pairs): the leaf is
+ * cut into K chunks of ck triangles, a pass tests R = 64 / ck (ray, chunk) sub-jobs at once, lane l holding triangle l % ck of
+ * sub-job l / ck.  rt_scene_create picks K for the best fill and stores the numbers where the record has room: the fourth
+ * components of normals[1..3] (a cone uses normals[0] only, explicit normals use three components each).
+ *   normals[1][3]  ck | K << 8 | R << 16   (0: the leaf is never tested pair-wise)
+ *   normals[2][3]  ceil(65536 / ck): (l * it) >> 16 == l / ck for l < 64
+ *   normals[3][3]  ceil(65536 / K) likewise for sub-job numbers below 4096 */
+#define RT_SEG_PAIR_WORD(g) __float_as_uint((g).normals[1][3])
+#define RT_SEG_PAIR_MCK(g) __float_as_uint((g).normals[2][3])
+#define RT_SEG_PAIR_MK(g) __float_as_uint((g).normals[3][3])
 struct alignas(16) DevSegment {
     uint32_t first, count; /* count == 0: inner node */
     uint32_t n_normals;    /* 0: plain leaf, always visited */

@@ -853,7 +853,13 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
     const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
 
-    __shared__ uint32_t rng_stage[RNG_LDS_SLOTS * 256u]; /* one wave per workgroup */
+    __shared__ __attribute__((aligned(16))) uint32_t rng_stage[RNG_LDS_SLOTS * 256u]; /* one wave per workgroup */
+#ifndef RT_DIST_NO_PAIRS
+    /* the pair-wise cast's scratch shares the staging area (a generator is refilled between casts, never during one): with
+     * 8 KB per wave the kernel sits exactly at five waves per SIMD, and anything on top would cost the fifth */
+    static_assert(sizeof(PairLds) <= sizeof(rng_stage), "PairLds must fit the staging area");
+    PairLds *const pair_lds = reinterpret_cast<PairLds *>(rng_stage);
+#endif
     Rng rng;
     rng.rec = rng.st = dp.rng_states;
     rng.index = 256u;
@@ -906,6 +912,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         r[3] = make_uint4(h.prim, 0u, 0u, 0u);
     };
 
+#ifdef RT_DIAG_PAIR_TIME /* per wave: [0] steps, [1..7] rt_cast.h, [8] the kernel */
+    unsigned long long diag_dt[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const unsigned long long diag_t0 = __builtin_readcyclecounter();
+#endif
     for (;;) {
         unsigned long long need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
         if (dp.n_epochs == 0u) need = 0ull;
@@ -947,15 +957,22 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         if (phase == DP_START) start_epoch();
 
         CastResult cr;
+#ifdef RT_DIST_NO_PAIRS /* A/B: every leaf wave-uniformly (round 2) */
         cr.prim = -1;
         cr.t = 0.0f;
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
-        if (phase != DP_DONE) {
-            cr = cast_asm(sc, req);
-            casts += 1u;
-        }
+        if (phase != DP_DONE) cr = cast_asm(sc, req);
+#else
+#ifdef RT_DIAG_PAIR_TIME
+        cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds, diag_dt);
+        diag_dt[0] += 1ull;
+#else
+        cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds); /* all lanes: the idle ones help with the others' pairs */
+#endif
+#endif
         if (phase == DP_DONE) continue;
+        casts += 1u;
 
 #include "rt_dist_advance.inc"
         if (!casting) { /* the chain of this (pixel, epoch) is over */
@@ -970,6 +987,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         }
     }
 
+#ifdef RT_DIAG_PAIR_TIME
+    diag_dt[8] = __builtin_readcyclecounter() - diag_t0;
+    if (lane == 0u) for (int q = 0; q < 9; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
+#endif
     if (dp.ray_count != nullptr) {
         uint32_t c = casts;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
@@ -1494,4 +1515,7 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
 } /* namespace rt */
 #ifdef RT_DIAG_NEED
 RT_DIAG_NEED_READER(rt_diag_read_need_dist)
+#endif
+#ifdef RT_DIAG_PAIR_TIME
+RT_DIAG_PAIR_TIME_READER(rt_diag_read_pair_time)
 #endif

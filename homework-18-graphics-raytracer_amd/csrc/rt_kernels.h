@@ -47,6 +47,7 @@ struct KernelScene {
     float filter_origin2; /* rays with |origin|^2 above this skip the bounding-sphere rejection (rt_device_scene.h) */
     const DevSegment *segments; /* the triangles as runs, clusters among them (rt_device_scene.h) */
     uint32_t n_segments;
+    const DevTriHead *heads;    /* plane + bounding sphere per triangle, for the pair-wise tests (rt_cast.h cast_pairs) */
 };
 
 /* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),

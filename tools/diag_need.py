@@ -38,7 +38,7 @@ for f in (lib.rt_diag_read_need_pwf, lib.rt_diag_read_need_dist):
 
 
 def report(name, reader):
-    buf = (C.c_ulonglong * 4)()
+    buf = (C.c_ulonglong * 96)()
     assert reader(buf, 1) == 0
     casts, tris, run, need = buf[0], buf[1], buf[2], buf[3]
     if casts == 0:
@@ -46,6 +46,18 @@ def report(name, reader):
         return
     print(f"{name}: {casts} wave-casts, {tris / casts:.1f} triangles visited per wave-cast, {run / max(tris, 1):.1f} active lanes; "
           f"lane-tests needed / run = {need / max(run, 1):.3f}  (needed {need / casts / 64:.1f} triangles per lane-cast of 64 lanes)")
+    if buf[4] or buf[9]:
+        hist = [buf[16 + n] for n in range(65)]
+        tot = max(sum(hist), 1)
+        cum, q = 0, {}
+        for n, v in enumerate(hist):
+            cum += v
+            for pct in (10, 25, 50, 75, 90, 99):
+                if pct not in q and cum * 100 >= pct * tot:
+                    q[pct] = n
+        print(f"    clustered leaves: {buf[4]} pair-wise ({buf[5] / max(buf[4], 1):.2f} passes each, {buf[6] / max(buf[5], 1):.2f} of the passes reach the signed areas "
+              f"with {buf[7] / max(buf[6], 1):.1f} pairs, {buf[8]} pairs accepted), {buf[9]} wave-uniform; lanes needing a leaf: percentiles {q}; "
+              f"casts redone for NaN {buf[10]}, with lanes missing {buf[11]}")
 
 
 world, cam = rt.reference_world(), rt.reference_camera()

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a wave of the chain kernel spends its time inside the pair-wise cast (build: make -C csrc variant
+TAG=ptime EXTRA=-DRT_DIAG_PAIR_TIME).  Accumulated per wave in registers, added up once when the wave leaves.
+
+    python tools/diag_pair_time.py [--epochs 8 --burn 32]
+"""
+import argparse
+import ctypes as C
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+from homework_18_graphics_raytracer_amd import _capi  # noqa: E402
+
+_capi._amd = None
+_orig = _capi._load
+_capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / "librt_amd_ptime.so")) if name == "librt_amd.so" else _orig(name)
+import homework_18_graphics_raytracer_amd as rt  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--epochs", type=int, default=8)
+ap.add_argument("--burn", type=int, default=32)
+a = ap.parse_args()
+lib = _capi.amd_lib()
+lib.rt_diag_read_pair_time.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+world, cam = rt.reference_world(), rt.reference_camera()
+frame = rt.Frame.full(a.width, a.height, a.depth)
+scene = rt.Scene(world)
+rng = rt.Rng(frame)
+accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+if a.burn:
+    rt.render_distributed(scene, cam, frame, rng, a.burn, accum=accum)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16)()
+assert lib.rt_diag_read_pair_time(buf, 1) == 0
+rt.render_distributed(scene, cam, frame, rng, a.epochs, accum=accum)
+torch.cuda.synchronize()
+assert lib.rt_diag_read_pair_time(buf, 1) == 0
+steps, total = buf[0], buf[8]
+names = {1: "classify nodes", 2: "wave-uniform runs", 3: "leaf set-up", 4: "pair passes", 5: "signed areas", 6: "finish"}
+print(f"chain kernel, {a.epochs} epochs after {a.burn}: {steps} wave-steps, {total / max(steps, 1):.0f} ticks per step, the cast {100.0 * buf[7] / max(total, 1):.1f} % of the wave time")
+print("  of the cast: " + ", ".join(f"{names[k]} {100.0 * buf[k] / max(buf[7], 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in range(1, 7)))
