@@ -125,7 +125,7 @@ DEFAULT_VARIANT = 18  # RT_VARIANT_PWF | RT_VARIANT_STATIC (csrc/rt_kernels.h)
 AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
-    "rt_get_variant", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_rng_state_words", "rt_rng_create",
+    "rt_get_variant", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_scene_describe_nodes", "rt_rng_state_words", "rt_rng_create",
     "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_multi_create", "rt_multi_destroy", "rt_multi_render_whitted_host", "rt_multi_render_distributed_host", "rt_post_process_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
 ]
 HOST_SYMBOLS = [
@@ -228,6 +228,7 @@ def amd_lib() -> C.CDLL:
         lib.rt_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint)]
         lib.rt_math_eval_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.rt_math_eval_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.rt_scene_describe_nodes.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
         _amd = lib
     return _amd
 

@@ -497,6 +497,32 @@ static int layout_scene(const rt_scene_desc *desc, SceneLayout &layout) {
             }
             i = j;
         }
+        /* Neighbouring clustered leaves whose common bounding sphere is hardly larger than the larger of their own become ONE leaf
+         * (the reference scene's two glass slabs, main.rs:879-977: 12 + 12 triangles an arm's length apart, the same three plane
+         * directions): a ray that needs one nearly always needs the other, and a leaf is a bounding-sphere test, a set of plane
+         * directions and — pair-wise — a set-up of its own.  A leaf is any run of consecutive triangles that all qualify for their own
+         * rejection, so nothing else changes.  Only leaves with the same ancestors are joined (no subtree ends between them). */
+        if (!clusters_off && getenv("RT_AMD_NO_LEAF_MERGE") == nullptr) {
+            for (size_t k = 0; k + 1u < segments.size();) {
+                const rt::DevSegment a = segments[k], b = segments[k + 1u];
+                bool ok = a.count != 0u && b.count != 0u && a.n_normals != 0u && b.n_normals != 0u && a.n_normals != RT_SEGMENT_CONE &&
+                          b.n_normals != RT_SEGMENT_CONE && a.first + a.count == b.first && a.count + b.count <= 64u;
+                for (size_t j = 0; ok && j < k; ++j) ok = !(segments[j].count == 0u && segments[j].skip_to == k + 1u);
+                rt::DevSegment g;
+                memset(&g, 0, sizeof g);
+                ok = ok && node_stats(a.first, b.first + b.count, &g) && g.n_normals != RT_SEGMENT_CONE &&
+                     g.r2_hi <= 1.15f * std::max(a.r2_hi, b.r2_hi);
+                if (!ok) { ++k; continue; }
+                g.first = a.first;
+                g.count = a.count + b.count;
+                g.skip_to = (uint32_t)k + 1u;
+                segments[k] = g;
+                segments.erase(segments.begin() + (ptrdiff_t)k + 1);
+                for (rt::DevSegment &n : segments)
+                    if (n.skip_to > k + 1u) n.skip_to -= 1u;
+                /* and again from the same node: it may take the next one too */
+            }
+        }
         /* clustered leaves: how their triangles are dealt to the lanes of a pair-wise pass (rt_device_scene.h RT_SEG_PAIR_*) */
         const bool pairs_off = getenv("RT_AMD_NO_PAIRS") != nullptr; /* A/B switch; results are the same either way */
         for (rt::DevSegment &g : segments) {

@@ -402,6 +402,7 @@ struct PairLds {
     uint32_t rank_lane[64];     /* the current leaf's needing lanes, in lane order */
     uint2 cand[RT_PAIR_CANDIDATES]; /* pairs that got as far as the signed areas: bits(t), owner lane | triangle << 6 */
     float4 heads[64][2];        /* the current leaf's DevTriHead records (a leaf tested pair-wise has 64 triangles at most) */
+    float4 kept[64];            /* per ray: n.d and the three signed areas of the pair that holds its key (what finish_hit needs of the winner) */
 };
 #ifndef RT_PAIR_MAX_NEED
 #define RT_PAIR_MAX_NEED 24u /* a clustered leaf that more lanes than this need is run wave-uniformly */
@@ -423,7 +424,9 @@ __device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray
     const int from = (int)(owner << 2);
     const V3 o = v3(pair_fetch(from, ray.o.x), pair_fetch(from, ray.o.y), pair_fetch(from, ray.o.z));
     const V3 d = v3(pair_fetch(from, ray.d.x), pair_fetch(from, ray.d.y), pair_fetch(from, ray.d.z));
-    bool nan_seen = false;
+    bool nan_seen = false, accepted = false;
+    unsigned long long key = ~0ull;
+    float4 mine_kept = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (mine) {
         const DevTri &T = sc.tris[tri];
         const float t = __uint_as_float(c.x);
@@ -434,13 +437,19 @@ __device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray
         const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
         if (!(a0 < 0.0f || a1 < 0.0f || a2 < 0.0f)) { /* NaN areas pass (main.rs:224) */
             nan_seen = t != t;
-            const unsigned long long key = ((unsigned long long)c.x << 32) | (unsigned long long)(0xffffffffu - tri);
+            accepted = true;
+            key = ((unsigned long long)c.x << 32) | (unsigned long long)(0xffffffffu - tri);
+            mine_kept = make_float4(dot(n, d), a0, a1, a2);
             __hip_atomic_fetch_min(&pl->key[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #ifdef RT_DIAG_NEED
             atomicAdd(&g_need_totals[8], 1ull);
 #endif
         }
     }
+    /* whoever holds its ray's key now leaves the winner's n.d and signed areas beside it (keys are unique per ray: one per triangle; a
+     * later, smaller key overwrites) */
+    pair_sync();
+    if (accepted && pl->key[owner] == key) pl->kept[owner] = mine_kept;
     return nan_seen;
 }
 
@@ -482,12 +491,10 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
 #define RT_PAIR_TICK(k)
 #endif
     TriBest best;
-    bool from_pairs;
     for (;;) {
         best.t = rtdm::quiet_nan();
         best.prim = -1;
         best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
-        from_pairs = false;
         if (!dense_only) pl->key[lane] = ~0ull;
         bool nan_seen = false;
         uint32_t n_cand = 0u; /* wave-uniform */
@@ -527,8 +534,13 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
                     const float ad = dot(v3(nrm[0].x, nrm[0].y, nrm[0].z), ray.d);
                     bool steep = cone ? ad * ad >= nrm[0].w * dd : rtdm::f_abs(ad) >= 1.0e-3f;
 #pragma unroll
-                    for (uint32_t q = 1; q < RT_SEGMENT_NORMALS; ++q)
+                    for (uint32_t q = 1; q < 4u; ++q)
                         steep = steep & ((rtdm::f_abs(dot(v3(nrm[q].x, nrm[q].y, nrm[q].z), ray.d)) >= 1.0e-3f) | (cone | (q >= n_normals)));
+                    if (!cone && n_normals > 4u) {
+#pragma unroll
+                        for (uint32_t q = 4u; q < RT_SEGMENT_NORMALS; ++q)
+                            steep = steep & ((rtdm::f_abs(dot(v3(nrm[q].x, nrm[q].y, nrm[q].z), ray.d)) >= 1.0e-3f) | (q >= n_normals));
+                    }
                     need = active & !(miss & steep);
                 }
                 needing = __builtin_amdgcn_ballot_w64(need);
@@ -663,9 +675,13 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
             const float kt = __uint_as_float((uint32_t)(key >> 32));
             const int32_t kp = (int32_t)(0xffffffffu - (uint32_t)key);
             if (best.prim < 0 || kt < best.t || (kt == best.t && kp > best.prim)) {
+                const float4 w = pl->kept[lane];
                 best.t = kt;
                 best.prim = kp;
-                from_pairs = true;
+                best.nd = w.x;
+                best.a0 = w.y;
+                best.a1 = w.z;
+                best.a2 = w.w;
             }
         }
         break;
@@ -675,7 +691,7 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
     cr.t = 0.0f;
     cr.bf = 0u;
     cr.a0 = cr.a1 = cr.a2 = 0.0f;
-    if (active) cr = cast_finish(sc, ray, best.t, best.prim, from_pairs ? nullptr : &best);
+    if (active) cr = cast_finish(sc, ray, best.t, best.prim, &best);
 #ifdef RT_DIAG_PAIR_TIME
     RT_PAIR_TICK(6)
     dt[7] += tick - tick0;

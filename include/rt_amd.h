@@ -343,6 +343,13 @@ typedef enum rt_math_op {
 int rt_math_eval_host(int op, const float *x, const float *y, float *out, size_t n);
 int rt_math_eval_device(int op, const float *h_x, const float *h_y, float *h_out, size_t n);
 
+/* The node array rt_scene_create builds over the triangles for the intersection loop (csrc/rt_device_scene.h: a pre-order
+ * array of leaves — runs of consecutive triangles — and inner nodes with skip pointers), computed on the host without
+ * touching a device: six words per node — first triangle, count (0: inner node), n_normals (0: plain leaf, always
+ * visited; 0xffffffff: a normal cone), skip_to, the pair-wise dealing word (chunk | chunks << 8 | sub-jobs per pass << 16; 0:
+ * never pair-wise), 0.  Writes at most cap_nodes nodes, always reports the count.  For tests of the builder's invariants. */
+int rt_scene_describe_nodes(const rt_scene_desc *desc, uint32_t *out_words, uint32_t cap_nodes, uint32_t *n_nodes);
+
 #ifdef __cplusplus
 }
 #endif

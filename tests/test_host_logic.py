@@ -176,3 +176,104 @@ def test_scene_file_validation(tmp_path):
         raise AssertionError("opened a missing file")
     except rt.RtError as e:
         assert "cannot open" in str(e)
+
+
+# ---- the node array of the intersection loop (csrc/rt_device_scene.h), built by rt_scene_create on the host ----
+
+def _nodes(desc):
+    lib = _capi.amd_lib()
+    n = C.c_uint32()
+    assert lib.rt_scene_describe_nodes(C.byref(desc), None, 0, C.byref(n)) == 0
+    buf = (C.c_uint32 * (6 * max(n.value, 1)))()
+    assert lib.rt_scene_describe_nodes(C.byref(desc), buf, n.value, C.byref(n)) == 0
+    return np.frombuffer(buf, dtype=np.uint32).reshape(-1, 6)[: n.value].copy()
+
+
+def _check_node_invariants(nodes, desc):
+    """Leaves tile the triangles in order; a leaf points at the next node; everything an inner node's skip_to jumps over belongs to
+    the inner node: a tree is built over ONE object's run of triangles, so a leaf below it holding another object's triangles
+    (appended to a leaf of a subtree that was already closed) would be skipped together with a node it has nothing to do with."""
+    n, n_triangles = len(nodes), desc.n_triangles
+    obj = np.array([desc.triangles[i].object_index for i in range(n_triangles)])
+    at = 0
+    for k, (first, count, _nn, skip_to, _pw, _z) in enumerate(nodes):
+        assert k < skip_to <= n
+        if count != 0:
+            assert first == at and skip_to == k + 1
+            at += count
+    assert at == n_triangles
+    for k, (first, count, _nn, skip_to, _pw, _z) in enumerate(nodes):
+        if count != 0:
+            continue
+        for j in range(k + 1, int(skip_to)):
+            jf, jc, _jn, js = (int(v) for v in nodes[j][:4])
+            assert js <= skip_to and jf >= first
+            assert np.all(obj[jf:jf + jc] == obj[first]), (k, j, nodes[k], nodes[j])
+
+
+def test_reference_scene_node_array():
+    d = rt.reference_world().desc()
+    nodes = _nodes(d)
+    _check_node_invariants(nodes, d)
+    leaves = [(int(f), int(c), int(nn)) for f, c, nn, *_ in nodes]
+    # the dodecahedron (6 plane directions), floor + wall (too large to bound: always visited), the two glass slabs joined
+    assert leaves == [(0, 36, 6), (36, 4, 0), (40, 24, 3)]
+    assert all(int(pw) != 0 for _f, _c, nn, _s, pw, _z in nodes if nn != 0)
+
+
+def _cap_world(seed, half_angle, tail):
+    """One object: a spherical cap of 240 triangles (15 leaves of 16) in random order — except that the LAST leaf is made of fifteen
+    triangles from one spot of the rim and one from the opposite spot: its normal cone, taken around its own mean normal, is nearly
+    twice as wide as the whole cap's, so it fails where its parent passes and becomes a plain leaf at the very end of the parent's
+    subtree.  Then `tail` objects of one square each: plain runs that start where that leaf ends."""
+    rng = np.random.default_rng(seed)
+    n_rings, n_seg = 8, 16
+    w = rt.World()
+    cap = w.push_object(_material())
+    tris, rim = [], []
+    pt = lambda th, ph: (0.5 * np.sin(th) * np.cos(ph), 0.5 * np.cos(th) + 0.5, 0.5 * np.sin(th) * np.sin(ph))
+    for r in range(n_rings):
+        t0, t1 = half_angle * r / n_rings, half_angle * (r + 1) / n_rings
+        for s in range(n_seg):
+            p0, p1 = 2 * np.pi * s / n_seg, 2 * np.pi * (s + 1) / n_seg
+            pair = [(pt(t0, p1), pt(t1, p0), pt(t1, p1))]
+            if r > 0:
+                pair.append((pt(t0, p0), pt(t1, p0), pt(t0, p1)))
+            for tri in pair:
+                tris.append(tri)
+                rim.append((r, s))
+    assert len(tris) == 240
+    near = sorted(range(240), key=lambda i: (-rim[i][0], min(rim[i][1], n_seg - rim[i][1])))[:15]  # outer rings, azimuth near 0
+    far = max(range(240), key=lambda i: (rim[i][0], -abs(rim[i][1] - n_seg // 2)))                  # outer ring, azimuth pi
+    last = near + [far]
+    rest = [i for i in rng.permutation(240) if i not in last]
+    for i in rest + last:
+        cap.push_flat_triangle([list(map(float, v)) for v in tris[i]], [[0.0, 0.0]] * 3)
+    for k in range(tail):
+        o = w.push_object(_material())
+        x = 0.3 * k
+        o.push_square([(x, 0.0, 1.0), (x, 0.0, 1.2), (x + 0.2, 0.0, 1.2), (x + 0.2, 0.0, 1.0)], [(0, 0), (0, 1), (1, 0), (0, 1)])
+    return w
+
+
+def _material():
+    m = _capi.Material()
+    m.normal = (0.0, 0.0, 1.0)
+    m.diffuse_color = (1.0, 1.0, 1.0)
+    return m
+
+
+def test_node_array_invariants_on_shuffled_meshes():
+    saw_plain_last_in_subtree = False
+    for seed in range(3):
+        for half_angle in (0.4, 0.5, 0.6):
+            w = _cap_world(seed, half_angle, 2)
+            d = w.desc()
+            nodes = _nodes(d)
+            _check_node_invariants(nodes, d)
+            for k, (first, count, nn, skip_to, *_r) in enumerate(nodes):
+                if count == 0:
+                    last = nodes[int(skip_to) - 1]
+                    saw_plain_last_in_subtree |= bool(last[1] != 0 and last[2] == 0)
+    # the case the builder once got wrong — a plain leaf closing a subtree, plain runs right behind it — must be in the sweep
+    assert saw_plain_last_in_subtree
