@@ -830,6 +830,12 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
  * Same operations on the same values as the fused kernel, so samples, flags, RNG states and cast counts are
  * bit-identical to it and to the oracle (tests/test_gpu_distributed_parity.py runs both). */
 
+/* The shade kernel keeps the wave-uniform cast: pair-wise (RT_DIST_SHADE_PAIRS) it is slower, 5.97 against 5.15 ms per 8-epoch batch —
+ * its shadow rays need the clusters less sparsely (half of the leaf visits have 8 lanes or more, a quarter 34 or more, against 7 and
+ * 25 in the chain kernel) and the 19 KB of PairLds per workgroup cost it two of its six waves per SIMD (profiles/r03p7_*). */
+#if !defined(RT_DIST_SHADE_PAIRS) && !defined(RT_DIST_SHADE_NO_PAIRS)
+#define RT_DIST_SHADE_NO_PAIRS
+#endif
 #ifndef RT_DIST_CHAIN_MIN_WAVES
 #define RT_DIST_CHAIN_MIN_WAVES 5 /* 96 VGPRs, no more scratch than at 4 (112); 3 / 4 / 5: 709 / 853 / 868 Msamples/s */
 #endif
@@ -912,9 +918,14 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         r[3] = make_uint4(h.prim, 0u, 0u, 0u);
     };
 
-#ifdef RT_DIAG_PAIR_TIME /* per wave: [0] steps, [1..7] rt_cast.h, [8] the kernel */
-    unsigned long long diag_dt[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#ifdef RT_DIAG_PAIR_TIME /* per wave: [0] steps, [1..7] rt_cast.h, [8] the kernel, [9] fetching work + shoot_focus, [10] after the cast: the hit and the
+                          * level's factor, [11] the level's draws and scatter_hit, [12] get_refract's exit, [13] the rest of the step */
+    unsigned long long diag_dt[14] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     const unsigned long long diag_t0 = __builtin_readcyclecounter();
+    unsigned long long diag_tick = diag_t0;
+#define RT_STEP_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); diag_dt[k] += now_ - diag_tick; diag_tick = now_; }
+#else
+#define RT_STEP_TICK(k)
 #endif
     for (;;) {
         unsigned long long need = __builtin_amdgcn_ballot_w64(phase == DP_DONE);
@@ -965,8 +976,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         if (phase != DP_DONE) cr = cast_asm(sc, req);
 #else
 #ifdef RT_DIAG_PAIR_TIME
+        RT_STEP_TICK(9)
         cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds, diag_dt);
         diag_dt[0] += 1ull;
+        diag_tick = __builtin_readcyclecounter();
 #else
         cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds); /* all lanes: the idle ones help with the others' pairs */
 #endif
@@ -985,11 +998,12 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
                 phase = DP_DONE;
             }
         }
+        RT_STEP_TICK(13)
     }
 
 #ifdef RT_DIAG_PAIR_TIME
     diag_dt[8] = __builtin_readcyclecounter() - diag_t0;
-    if (lane == 0u) for (int q = 0; q < 9; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
+    if (lane == 0u) for (int q = 0; q < 14; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
 #endif
     if (dp.ray_count != nullptr) {
         uint32_t c = casts;
@@ -997,6 +1011,9 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         if (lane == 0u && c != 0u) atomicAdd(dp.ray_count, (unsigned long long)c);
     }
 }
+
+#undef RT_STEP_TICK
+#define RT_STEP_TICK(k) /* the diagnostic ticks are the persistent-lane chain kernel's */
 
 /* ---- the chain as a kernel of workgroup-local queues ("queued chain") -----------------------------------------------
  * dist_chain_kernel keeps a lane on one pixel: after a few steps the 64 lanes of a wave sit in all phases of the chain at
@@ -1080,6 +1097,9 @@ __global__ __launch_bounds__(CQ_THREADS, CQ_MIN_WAVES) void dist_chainq_kernel(c
         S.tiles_exhausted = 0u;
         S.idle = S.gen = S.done = 0u;
     }
+#ifdef RT_CQ_PAIRS
+    __shared__ PairLds cq_pairs[CQ_WAVES];
+#endif
     __syncthreads();
     uint32_t casts = 0u;
 
@@ -1227,10 +1247,15 @@ __global__ __launch_bounds__(CQ_THREADS, CQ_MIN_WAVES) void dist_chainq_kernel(c
         cr.t = 0.0f;
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
+#ifdef RT_CQ_PAIRS /* A/B: the pair-wise cast in the queued organisation too */
+        cr = cast_pairs(sc, req, phase != DP_DONE, &cq_pairs[threadIdx.x >> 6]);
+        if (phase != DP_DONE) casts += 1u;
+#else
         if (phase != DP_DONE) {
             cr = cast_asm(sc, req);
             casts += 1u;
         }
+#endif
 
         bool finished_pixel = false;
         if (phase != DP_DONE) {
@@ -1309,6 +1334,10 @@ int distributed_chainq_workgroups_per_cu(void) {
 #endif
 __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
+#ifndef RT_DIST_SHADE_NO_PAIRS
+    __shared__ PairLds pair_lds_all[RT_DIST_SHADE_THREADS / 64u];
+    PairLds *const pair_lds = &pair_lds_all[threadIdx.x >> 6];
+#endif
     uint32_t *const bucket_start = shade_lds + 1u, *const bucket_cursor = bucket_start + DIST_SHADE_BUCKETS;
     uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */
     uint32_t *const shade_list = unsorted + list_cap;            /* the same, bucket by bucket */
@@ -1388,13 +1417,25 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
                 need = !(cosine <= 0.0f);
             }
             if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+            Ray req;
+            req.o = pos;
+            req.d = -dl.direction;
+            req.mode = FACE_BACK;
+            req.excl = pack_excl(prim, FACE_BACK);
+#ifdef RT_DIST_SHADE_NO_PAIRS /* A/B */
+            CastResult cr;
+            cr.prim = -1;
+            cr.t = 0.0f;
+            cr.bf = 0u;
+            cr.a0 = cr.a1 = cr.a2 = 0.0f;
+            if (need) cr = cast_asm(sc, req);
+#elif defined(RT_DIAG_PAIR_TIME)
+            unsigned long long diag_dt[9];
+            const CastResult cr = cast_pairs(sc, req, need, pair_lds, diag_dt);
+#else
+            const CastResult cr = cast_pairs(sc, req, need, pair_lds); /* all lanes: those without a shadow ray help with the others' pairs */
+#endif
             if (need) {
-                Ray req;
-                req.o = pos;
-                req.d = -dl.direction;
-                req.mode = FACE_BACK;
-                req.excl = pack_excl(prim, FACE_BACK);
-                const CastResult cr = cast_asm(sc, req);
                 casts += 1u;
                 bool lit = true;
                 if (cr.prim >= 0) {

@@ -15,9 +15,11 @@ import torch  # noqa: E402
 
 from homework_18_graphics_raytracer_amd import _capi  # noqa: E402
 
+LIB = next((x.split("=", 1)[1] for x in sys.argv if x.startswith("--lib=")), "ptime")
+sys.argv = [x for x in sys.argv if not x.startswith("--lib=")]
 _capi._amd = None
 _orig = _capi._load
-_capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / "librt_amd_ptime.so")) if name == "librt_amd.so" else _orig(name)
+_capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / ("librt_amd_" + LIB + ".so"))) if name == "librt_amd.so" else _orig(name)
 import homework_18_graphics_raytracer_amd as rt  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -45,4 +47,7 @@ assert lib.rt_diag_read_pair_time(buf, 1) == 0
 steps, total = buf[0], buf[8]
 names = {1: "classify nodes", 2: "wave-uniform runs", 3: "leaf set-up", 4: "pair passes", 5: "signed areas", 6: "finish"}
 print(f"chain kernel, {a.epochs} epochs after {a.burn}: {steps} wave-steps, {total / max(steps, 1):.0f} ticks per step, the cast {100.0 * buf[7] / max(total, 1):.1f} % of the wave time")
+if buf[9] or buf[10]:
+    step = {9: "fetching work + shoot_focus", 10: "the hit + the level's factor", 12: "the level's draws + scatter_hit | get_refract's exit", 13: "the rest"}
+    print("  outside the cast: " + ", ".join(f"{step[k]} {100.0 * buf[k] / max(total, 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in (9, 10, 12, 13)))
 print("  of the cast: " + ", ".join(f"{names[k]} {100.0 * buf[k] / max(buf[7], 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in range(1, 7)))
