@@ -428,7 +428,7 @@ def main() -> int:
             dist.all_reduce(el2, op=dist.ReduceOp.MAX)
             dist.all_reduce(c2, op=dist.ReduceOp.SUM)
         if rank == 0:
-            same2 = bool(torch.equal(bands2[0].view(torch.int32), band.view(torch.int32))) if not distributed else None
+            same2 = all(bool(torch.equal(b.view(torch.int32), band.view(torch.int32))) for b in bands2) if not distributed else None
             pipelined = {"frames_in_flight": 2, "value": round(int(c2.item()) / float(el2.item()) / 1e6, 3), "unit": "Mrays/s",
                          "ms_per_frame": round(float(el2.item()) * 1e3 / args.steps, 4), "steps": args.steps,
                          "frames_bit_identical_to_the_headline_run": same2,

@@ -126,7 +126,7 @@ AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
     "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
     "rt_get_variant", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_scene_describe_nodes", "rt_rng_state_words", "rt_rng_create",
-    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_multi_create", "rt_multi_destroy", "rt_multi_render_whitted_host", "rt_multi_render_distributed_host", "rt_post_process_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
+    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_multi_create", "rt_multi_destroy", "rt_multi_render_whitted_host", "rt_multi_render_distributed_host", "rt_multi_render_whitted", "rt_multi_render_distributed", "rt_post_process_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
@@ -211,6 +211,9 @@ def amd_lib() -> C.CDLL:
         lib.rt_multi_render_whitted_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_ulonglong)]
         lib.rt_multi_render_distributed_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_float, C.c_float, C.c_uint32,
                                                          C.c_void_p, C.POINTER(C.c_ulonglong)]
+        lib.rt_multi_render_whitted.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_multi_render_distributed.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_float, C.c_float, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_post_process_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_encode_srgb8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_accumulate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]

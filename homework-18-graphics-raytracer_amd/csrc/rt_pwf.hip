@@ -905,7 +905,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 atomicExch(pp.global + PW_G_OVERFLOW, 1u);
             }
             if (overflow == 0u && pp.ray_count != nullptr)
-                *pp.ray_count += __hip_atomic_load(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(pp.ray_count, /* atomic: a caller may hand one counter to renders on several streams (include/rt_amd.h: "added to") */
+                          __hip_atomic_load(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             for (uint32_t k = 0; k < PW_G_BLOCK_WORDS; ++k) pp.global_next[k] = 0u;
         }
     }

@@ -262,6 +262,16 @@ int rt_multi_render_whitted_host(rt_multi *m, const rt_camera *camera, const rt_
  * starts new ones. */
 int rt_multi_render_distributed_host(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float focus, float blur, uint32_t n_epochs,
                                      float *h_accum, unsigned long long *h_ray_count);
+/* The same two, device-resident: the frame is assembled in DEVICE memory on devices[0] (d_rgb / d_accum: rt_frame_pixels * 3
+ * floats there; d_ray_count, may be NULL, a u64 there that the casts of all devices are ADDED to), so that
+ * rt_post_process_device and rt_encode_srgb8_device can follow on `hip_stream` (a stream of devices[0]) without a trip
+ * through host memory.  A band of another device travels by hipMemcpyPeerAsync (xGMI) into a staging buffer on devices[0]
+ * and is de-interleaved there; no RCCL, no host bounce.  Asynchronous like rt_render_whitted: on return everything is
+ * enqueued; work on `hip_stream` after the call sees the finished frame.  rt_multi_render_distributed continues from the
+ * sums already in d_accum (main.rs:1165), exactly as rt_render_distributed does.  Replaces main.rs:1105-1109 / 1162-1167. */
+int rt_multi_render_whitted(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float *d_rgb, unsigned long long *d_ray_count, void *hip_stream);
+int rt_multi_render_distributed(rt_multi *m, const rt_camera *camera, const rt_frame *frame, float focus, float blur, uint32_t n_epochs,
+                                float *d_accum, unsigned long long *d_ray_count, void *hip_stream);
 
 /* ---- the step after the path, on the device --------------------
 

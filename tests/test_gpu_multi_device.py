@@ -72,6 +72,50 @@ def test_stochastic_loop_over_a_device_list_is_the_reference_loop():
         lib.rt_multi_destroy(m)
 
 
+@pytest.mark.parametrize("stage", [False, True])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_device_resident_frame_over_a_device_list(devices, stage, monkeypatch):
+    """rt_multi_render_whitted / rt_multi_render_distributed: the frame is assembled in device memory (no host bounce), so that
+    rt_post_process_device can follow on the same stream — main()'s whole loop without the image leaving the GPUs.  `stage`
+    forces every band through the staging buffer + hipMemcpyPeerAsync route that a second physical device would take."""
+    import torch
+
+    if stage:
+        monkeypatch.setenv("RT_AMD_MULTI_FORCE_STAGE", "1")
+    lib = _capi.amd_lib()
+    world, cam = rt.reference_world(), rt.reference_camera()
+    desc = world.desc()
+    frame = rt.Frame.full(96, 70, 5)
+    m = _multi(desc, devices)
+    try:
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            img = torch.zeros((70, 96, 3), dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        stream.synchronize()
+        sp = C.c_void_p(stream.cuda_stream)
+        _capi.check(lib.rt_multi_render_whitted(m, C.byref(cam), C.byref(frame), C.c_void_p(img.data_ptr()), C.c_void_p(cnt.data_ptr()), sp))
+        _capi.check(lib.rt_post_process_device(C.c_void_p(img.data_ptr()), 70 * 96, None, sp))
+        want, wcasts = _oracle.render_whitted(desc, cam, frame)
+        _oracle.post_process(want)
+        st = _oracle.rng_init(frame)
+        total = wcasts
+        for epochs in (1, 2):
+            _capi.check(lib.rt_multi_render_distributed(m, C.byref(cam), C.byref(frame), 3.0, 0.04, epochs, C.c_void_p(img.data_ptr()), C.c_void_p(cnt.data_ptr()), sp))
+            _capi.check(lib.rt_post_process_device(C.c_void_p(img.data_ptr()), 70 * 96, None, sp))
+            s, v, c = _oracle.render_distributed(desc, cam, frame, st, epochs)
+            for e in range(epochs):
+                want += np.where(v[e][..., None] != 0, s[e], np.float32(0))
+            _oracle.post_process(want)
+            total += c
+        stream.synchronize()
+        assert np.array_equal(img.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert int(cnt.item()) == total
+        assert torch.cuda.current_device() == 0
+    finally:
+        lib.rt_multi_destroy(m)
+
+
 def test_argument_validation():
     lib = _capi.amd_lib()
     desc = rt.reference_world().desc()
@@ -79,3 +123,5 @@ def test_argument_validation():
     assert lib.rt_multi_create(C.byref(desc), (C.c_int * 1)(7), 1, C.byref(h)) == -1 and b"device" in lib.rt_last_error()
     assert lib.rt_multi_create(C.byref(desc), None, 0, C.byref(h)) == -1
     assert lib.rt_multi_render_whitted_host(None, None, None, None, None) == -1
+    assert lib.rt_multi_render_whitted(None, None, None, None, None, None) == -1
+    assert lib.rt_multi_render_distributed(None, None, None, 3.0, 0.04, 1, None, None, None) == -1
