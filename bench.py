@@ -95,8 +95,29 @@ def cpu_baseline(world_desc, camera, width, height, depth, threads, gpu_frame):
 STOCHASTIC_EPOCHS = 64  # BASELINE.json configs[3]: 64 depth-of-field samples per pixel
 
 
+SCATTER_EPOCHS = 5      # BASELINE.json configs[4] / SURVEY §8(d) "Config 5": 10 368 000 = 1920 x 1080 x 5 (pixel, epoch) samples
+
+
+def hbm_view(counter_bytes, alg_bytes, ms, rec):
+    """north_star: "achieved HBM GB/s and L2-hit rate".  `achieved` is what HBM SAW — FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of the
+    committed rocprofv3 --pmc profile of this very workload, over the live kernel time; the algorithmic bytes sit
+    beside it under their own name.  None when no committed profile matches the configuration."""
+    out = {"achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+           "algorithmic": {"bytes_per_launch": alg_bytes, "GB_per_s": round(alg_bytes / (ms * 1e-3) / 1e9, 3),
+                           "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6)},
+           "l2_hit_rate": None, "source": None}
+    if counter_bytes:
+        gbs = counter_bytes / (ms * 1e-3) / 1e9
+        out.update({"achieved": round(gbs, 2), "frac": round(gbs / PEAK_HBM_GBS, 5), "counter_bytes_per_launch": counter_bytes,
+                    "counter_over_algorithmic": round(counter_bytes / alg_bytes, 2)})
+    if rec:
+        out["l2_hit_rate"] = rec.get("l2_hit_rate")
+        out["source"] = rec.get("source")
+    return out
+
+
 def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distributed, world_desc=None, cpu_threads=0,
-                    epochs=STOCHASTIC_EPOCHS):
+                    epochs=STOCHASTIC_EPOCHS, config="configs[3]", traffic_file="traffic_stochastic.json"):
     """The other render loop of the reference (shoot_focus + distributed_ray_trace, main.rs:1117-1167) as BASELINE.json
     configs[3] states it: 64 samples per pixel of the 1920x1080 depth-8 frame, image rows sharded over the ranks, the
     accumulated bands gathered to rank 0 over RCCL.  ONE convention for every number of this pass: the whole job from
@@ -159,25 +180,27 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
            "value": round(samples / elapsed / 1e6, 2), "unit": "Msamples/s", "n_gpus": world_size,
            "ms_per_epoch": round(elapsed * 1e3 / epochs, 4), "ms_total": round(elapsed * 1e3, 3),
            "Mrays_per_s": round(casts / elapsed / 1e6, 2), "casts_per_sample": round(casts / samples, 3),
-           "config": {"workload": f"configs[3]: {epochs} depth-of-field samples per pixel, {width}x{height}, depth {depth}, focus 3.0, blur 0.04, "
+           "config": {"workload": f"{config}: {epochs} depth-of-field samples per pixel ({samples} (pixel, epoch) samples), {width}x{height}, depth {depth}, focus 3.0, blur 0.04, "
                                   f"streams seeded y*2^33+x, interleaved rows over {world_size} rank(s)" + (", accumulators gathered to rank 0 over RCCL inside the timed region" if distributed else ""),
-                      "epochs": epochs},
+                      "epochs": epochs, "samples": samples},
            "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tflops / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
-                        "kernel": "the pass's four kernels together (rng look-ahead, dist_chain_kernel, dist_shade_kernel, dist_unwind_kernel); dist_chain_kernel is ~60 % of it",
+                        "kernel": "the pass's four kernels together (rng look-ahead, dist_chain_kernel, dist_shade_kernel, dist_unwind_kernel); dist_chain_kernel is ~55 % of it",
                         "render_ms": round(render_ms, 3), "flop_per_cast": flop_per_cast, "casts_per_launch": casts_rank,
-                        "note": "algorithmic flop = casts x (T x 77 + S x 28): an upper bound on useful work, as for the Whitted pass",
-                        "hbm": {"achieved": round(alg_bytes / (render_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(alg_bytes / (render_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes}},
+                        "note": "algorithmic flop = casts x (T x 77 + S x 28): an upper bound on useful work, as for the Whitted pass"},
            "parity": "tests/test_gpu_distributed_parity.py, tests/test_gpu_reference_pins.py"}
-    tpath = ROOT / "profiles" / "traffic_stochastic.json"
+    rec = None
+    tpath = ROOT / "profiles" / traffic_file
     if tpath.exists():
         try:
             rec = json.loads(tpath.read_text())
-            if rec.get("width") == width and rec.get("height") == height and rec.get("depth") == depth and rec.get("epochs") == epochs and world_size == 1:
-                out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+            if not (rec.get("width") == width and rec.get("height") == height and rec.get("depth") == depth and rec.get("epochs") == epochs and world_size == 1):
+                rec = None
         except Exception:
-            pass
+            rec = None
+    if rec:
+        out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+    out["roofline"]["hbm"] = hbm_view(rec.get("hbm_bytes_per_launch") if rec else None, alg_bytes, render_ms, rec)
     if world_desc is not None and world_size == 1:
         # the oracle's restatement of the same loop on the host cores: the FIRST epoch of the same frame; the GPU's first
         # epoch (fresh streams, same seeds) must equal it bit for bit
@@ -315,13 +338,14 @@ def main() -> int:
         casts_this_rank = int(count.item()) // max(1, args.steps)
         achieved_tflops = casts_this_rank * flop_per_cast / (kernel_ms_max * 1e-3) / 1e12
         alg_hbm_bytes = frame.rows * frame.cols * 12 + 6752  # 12 B/pixel out + the scene once
-        traffic, executed = None, None
+        traffic, executed, traffic_rec = None, None, None
         tpath = ROOT / "profiles" / "traffic.json"
         if tpath.exists():
             try:
                 rec = json.loads(tpath.read_text())
                 if rec.get("width") == W and rec.get("height") == H and rec.get("depth") == D and world_size == 1 and rec.get("variant", 2) == variant:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_rec = rec
                     if rec.get("sq_insts_valu"):
                         # executed VALU work from the SQ_INSTS_VALU counter of the committed profile (wave-instructions x 64
                         # lanes), against the issue roof of a path that may not fuse multiply-add: half the FMA peak
@@ -362,25 +386,19 @@ def main() -> int:
                 "frac": round(achieved_tflops / PEAK_FP32_VECTOR_TFLOPS, 5),
                 "traffic": traffic,
                 "executed_valu": executed,
-                "kernel": "rt::pwf_kernel (the persistent render kernel; its two one-thread bookkeeping launches are in call_ms_avg)" if variant & 16
+                "kernel": "rt::pwf_kernel (the persistent render kernel: one launch per frame; the no-op fallback launch behind it is in call_ms_avg)" if variant & 16
                           else "rt::whitted_kernel<8, %s>" % ("true" if variant & 1 else "false"),
                 "kernel_ms_avg": round(kernel_ms_max, 4),
                 "call_ms_avg": round(call_ms, 4),
                 "flop_per_cast": flop_per_cast,
                 "casts_per_launch": casts_this_rank,
                 "note": "no MFMA and not HBM-bound: the scene is 6.75 KB, the binding roof is FP32 vector issue "
-                        "(SURVEY §8d); hbm below is the algorithmic-bytes view the north_star asks for. `achieved` counts "
+                        "(SURVEY §8d); hbm below is what the counters of the committed profile saw, the algorithmic bytes beside it. `achieved` counts "
                         "ALGORITHMIC flop — casts x (T x 77 + S x 28), as if every cast ran every primitive test — i.e. an "
                         "upper bound on useful work: the kernel's conservative rejections skip more than half of it, and "
                         "the path may not use FMA (parity). Executed VALU work is in executed_valu (from SQ_INSTS_VALU, "
                         "profiles/)",
-                "hbm": {
-                    "achieved": round(alg_hbm_bytes / (kernel_ms_max * 1e-3) / 1e9, 3),
-                    "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s",
-                    "frac": round(alg_hbm_bytes / (kernel_ms_max * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
-                    "algorithmic_bytes_per_launch": alg_hbm_bytes,
-                },
+                "hbm": hbm_view(traffic, alg_hbm_bytes, kernel_ms_max, traffic_rec),
             },
         }
         if not args.no_cpu_baseline and world_size == 1:
@@ -439,12 +457,21 @@ def main() -> int:
     if not args.no_stochastic:
         stochastic = stochastic_pass(scene, camera, W, H, D, rank, world_size, distributed,
                                      world_desc=None if args.no_cpu_baseline else desc, cpu_threads=args.cpu_threads)
+    # configs[4] ("photon.rs scatter pass: 10M photons" = SURVEY §8(d) Config 5): 10 368 000 (pixel, epoch) samples of
+    # distributed_ray_trace — 5 epochs of the same frame, the same convention (fresh streams, one call, gather inside the timed region)
+    scatter = None
+    if not args.no_stochastic:
+        scatter = stochastic_pass(scene, camera, W, H, D, rank, world_size, distributed, world_desc=None, epochs=SCATTER_EPOCHS,
+                                  config="configs[4], the scatter pass", traffic_file="traffic_scatter.json")
     status = 0
     if rank == 0:
         if pipelined is not None:
             line["pipelined"] = pipelined
         if stochastic is not None:
             line["stochastic_pass"] = stochastic
+        if scatter is not None:
+            scatter["parity"] = "tests/test_gpu_distributed_parity.py::test_scatter_job_of_configs4_equals_the_oracle (the whole job: samples, flags, generator records, casts)"
+            line["scatter_pass"] = scatter
         print(json.dumps(line), flush=True)
         # a fast frame that differs from the reference algorithm's is not a result: fail loudly
         if line.get("cpu_baseline", {}).get("gpu_frame_bit_identical_to_cpu") is False:

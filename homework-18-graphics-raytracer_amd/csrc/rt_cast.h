@@ -273,6 +273,48 @@ __device__ __forceinline__ bool cluster_skippable(const Segment &g, const Ray &r
     return __builtin_amdgcn_ballot_w64(steep) == __builtin_amdgcn_ballot_w64(true);
 }
 
+/* A node's record in ONE round trip: its head and all eight normal slots, scalar loads issued together.  (Read field by field
+ * the compiler fetches each where it is first needed — the head, then one normal per trip of a loop — one round trip after the
+ * other.) */
+struct NodeRec {
+    u32x4 h0, h1; /* first, count, n_normals, r2_hi | c[3], skip_to */
+    float4 nrm[RT_SEGMENT_NORMALS];
+};
+__device__ __forceinline__ NodeRec load_node(const DevSegment *node) {
+    const RT_UNIFORM u32x4 *gp = reinterpret_cast<const RT_UNIFORM u32x4 *>(reinterpret_cast<uintptr_t>(node));
+    NodeRec r;
+    r.h0 = gp[0];
+    r.h1 = gp[1];
+#pragma unroll
+    for (uint32_t q = 0; q < RT_SEGMENT_NORMALS; ++q) {
+        const u32x4 w = gp[2u + q];
+        r.nrm[q] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    }
+    return r;
+}
+/* cluster_skippable_lane in two halves: the ray's line misses the node's sphere (and the ray may use the rejections at all) ... */
+__device__ __forceinline__ bool node_missed(const NodeRec &g, const Ray &ray, const CastMasks &m, uint32_t lane) {
+    const V3 disp = v3(__uint_as_float(g.h1.x), __uint_as_float(g.h1.y), __uint_as_float(g.h1.z)) - ray.o;
+    const V3 cr = cross(disp, ray.d);
+    return ((m.filter_ok >> lane) & 1ull) != 0ull && dot(cr, cr) > __uint_as_float(g.h0.w) * dot(ray.d, ray.d);
+}
+/* ... and it is not (nearly) parallel to a plane below the node: without a branch per normal */
+__device__ __forceinline__ bool node_steep(const NodeRec &g, const Ray &ray) {
+    const uint32_t n_normals = g.h0.z;
+    const bool cone = n_normals == RT_SEGMENT_CONE;
+    const float ad = dot(v3(g.nrm[0].x, g.nrm[0].y, g.nrm[0].z), ray.d);
+    bool steep = cone ? ad * ad >= g.nrm[0].w * dot(ray.d, ray.d) : rtdm::f_abs(ad) >= 1.0e-3f;
+#pragma unroll
+    for (uint32_t q = 1; q < 4u; ++q)
+        steep = steep & ((rtdm::f_abs(dot(v3(g.nrm[q].x, g.nrm[q].y, g.nrm[q].z), ray.d)) >= 1.0e-3f) | (cone | (q >= n_normals)));
+    if (!cone && n_normals > 4u) {
+#pragma unroll
+        for (uint32_t q = 4u; q < RT_SEGMENT_NORMALS; ++q)
+            steep = steep & ((rtdm::f_abs(dot(v3(g.nrm[q].x, g.nrm[q].y, g.nrm[q].z), ray.d)) >= 1.0e-3f) | (q >= n_normals));
+    }
+    return steep;
+}
+
 /* Everything of World::cast after the triangle loop: the winner's backface flag and signed areas, then the
  * sphere loop (main.rs:264-324), starting from the triangles' nearest hit. */
 __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim,
@@ -332,45 +374,58 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
 
 __device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
     const CastMasks m = cast_masks(ray, sc.filter_origin2);
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     TriBest best;
     best.t = rtdm::quiet_nan();
     best.prim = -1;
     best.nd = best.a0 = best.a1 = best.a2 = 0.0f;
     /* The triangles in index order: a walk over the node array (rt_device_scene.h) — a node that no lane can hit is left
      * out together with everything below it, an inner node that somebody may hit is descended into, and the triangles of
-     * neighbouring leaves that are visited go through the loop in one call (its set-up and first fetches are paid once). */
+     * neighbouring leaves that are visited go through the loop in one call (its set-up and first fetches are paid once; the loop
+     * is instantiated once). */
     uint32_t run_first = 0u, run_count = 0u;
     const uint32_t n_nodes = sc.n_segments;
 #ifdef RT_DIAG_NEED
-    {
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u) atomicAdd(&g_need_totals[0], 1ull);
-    }
+    const unsigned long long diag_act = __builtin_amdgcn_ballot_w64(true);
+    const bool diag_first = __builtin_amdgcn_mbcnt_hi((uint32_t)(diag_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)diag_act, 0u)) == 0u;
+    if (diag_first) atomicAdd(&g_need_totals[0], 1ull);
 #endif
-    for (uint32_t k = 0; k < n_nodes;) {
-        const auto &g = uniform_ref(sc.segments + k);
-        if (g.n_normals != 0u && cluster_skippable(g, ray, m)) {
-            if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
-            run_count = 0u;
-            k = g.skip_to;
-            continue;
-        }
-        k += 1u;
-        if (g.count == 0u) continue; /* an inner node somebody may hit: on to its children */
-#ifdef RT_DIAG_NEED
-        {
-            const unsigned long long act = __builtin_amdgcn_ballot_w64(true), need = __builtin_amdgcn_ballot_w64(!cluster_skippable_lane(g, ray, m));
-            if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u) {
-                atomicAdd(&g_need_totals[1], (unsigned long long)g.count);
-                atomicAdd(&g_need_totals[2], (unsigned long long)g.count * (unsigned long long)__builtin_popcountll(act));
-                atomicAdd(&g_need_totals[3], (unsigned long long)g.count * (unsigned long long)__builtin_popcountll(need));
+    for (uint32_t k = 0;;) {
+        bool skip = false, leaf = false, more = k < n_nodes;
+        uint32_t g_first = 0u, g_count = 0u, next_k = k;
+        if (more) {
+            const NodeRec g = load_node(sc.segments + k);
+            g_first = g.h0.x;
+            g_count = g.h0.y;
+            if (g.h0.z != 0u) { /* the normals only if every lane's line misses the sphere */
+                const bool missed = node_missed(g, ray, m, lane);
+                if (__builtin_amdgcn_ballot_w64(!missed) == 0ull) skip = __builtin_amdgcn_ballot_w64(!node_steep(g, ray)) == 0ull;
             }
-        }
+            leaf = !skip && g_count != 0u;
+            next_k = skip ? g.h1.w : k + 1u;
+#ifdef RT_DIAG_NEED
+            if (leaf) {
+                const unsigned long long need = __builtin_amdgcn_ballot_w64(!(g.h0.z != 0u && node_missed(g, ray, m, lane) && node_steep(g, ray)));
+                if (diag_first) {
+                    atomicAdd(&g_need_totals[1], (unsigned long long)g_count);
+                    atomicAdd(&g_need_totals[2], (unsigned long long)g_count * (unsigned long long)__builtin_popcountll(diag_act));
+                    atomicAdd(&g_need_totals[3], (unsigned long long)g_count * (unsigned long long)__builtin_popcountll(need));
+                }
+            }
 #endif
-        if (run_count == 0u) run_first = g.first;
-        run_count += g.count; /* leaves are contiguous in triangle order unless something was skipped in between (then the run was closed) */
+        }
+        /* the run gathered so far, when what comes next is not its continuation */
+        if (run_count != 0u && (!more || skip || (leaf && run_first + run_count != g_first))) {
+            cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
+            run_count = 0u;
+        }
+        if (!more) break;
+        k = next_k;
+        if (leaf) {
+            if (run_count == 0u) run_first = g_first;
+            run_count += g_count;
+        }
     }
-    if (run_count != 0u) cast_asm_triangles(sc.tris + run_first, run_count, run_first, ray, m, &best);
     return cast_finish(sc, ray, best.t, best.prim, &best);
 }
 
@@ -508,40 +563,18 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
             bool need = false;
             unsigned long long needing = 0ull;
             if (k < n_nodes) {
-                /* the node's record in one round trip: its head and all eight normal slots (scalar loads, issued together; read
-                 * field by field the compiler fetches each where it is first needed, one round trip after the other) */
-                const RT_UNIFORM u32x4 *gp = reinterpret_cast<const RT_UNIFORM u32x4 *>(reinterpret_cast<uintptr_t>(sc.segments + k));
-                const u32x4 h0 = gp[0], h1 = gp[1];
-                float4 nrm[RT_SEGMENT_NORMALS];
-#pragma unroll
-                for (uint32_t q = 0; q < RT_SEGMENT_NORMALS; ++q) {
-                    const u32x4 w = gp[2u + q];
-                    nrm[q] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-                }
-                g_first = h0.x;
-                g_count = h0.y;
-                const uint32_t n_normals = h0.z;
-                pair_word = __float_as_uint(nrm[1].w);
-                pair_mck = __float_as_uint(nrm[2].w);
-                pair_mk = __float_as_uint(nrm[3].w);
+                const NodeRec g = load_node(sc.segments + k);
+                g_first = g.h0.x;
+                g_count = g.h0.y;
+                const uint32_t n_normals = g.h0.z;
+                pair_word = __float_as_uint(g.nrm[1].w);
+                pair_mck = __float_as_uint(g.nrm[2].w);
+                pair_mk = __float_as_uint(g.nrm[3].w);
+                const u32x4 h1 = g.h1;
                 need = active;
-                if (n_normals != 0u) { /* cluster_skippable_lane, without a branch per normal */
-                    const V3 disp = v3(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z)) - ray.o;
-                    const V3 cr = cross(disp, ray.d);
-                    const float dd = dot(ray.d, ray.d);
-                    const bool miss = ((m.filter_ok >> lane) & 1ull) != 0ull && dot(cr, cr) > __uint_as_float(h0.w) * dd;
-                    const bool cone = n_normals == RT_SEGMENT_CONE;
-                    const float ad = dot(v3(nrm[0].x, nrm[0].y, nrm[0].z), ray.d);
-                    bool steep = cone ? ad * ad >= nrm[0].w * dd : rtdm::f_abs(ad) >= 1.0e-3f;
-#pragma unroll
-                    for (uint32_t q = 1; q < 4u; ++q)
-                        steep = steep & ((rtdm::f_abs(dot(v3(nrm[q].x, nrm[q].y, nrm[q].z), ray.d)) >= 1.0e-3f) | (cone | (q >= n_normals)));
-                    if (!cone && n_normals > 4u) {
-#pragma unroll
-                        for (uint32_t q = 4u; q < RT_SEGMENT_NORMALS; ++q)
-                            steep = steep & ((rtdm::f_abs(dot(v3(nrm[q].x, nrm[q].y, nrm[q].z), ray.d)) >= 1.0e-3f) | (q >= n_normals));
-                    }
-                    need = active & !(miss & steep);
+                if (n_normals != 0u) { /* cluster_skippable_lane */
+                    const bool missed = node_missed(g, ray, m, lane), steep = node_steep(g, ray);
+                    need = active && !(missed && steep);
                 }
                 needing = __builtin_amdgcn_ballot_w64(need);
                 n_need = (uint32_t)__builtin_popcountll(needing);

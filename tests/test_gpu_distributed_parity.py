@@ -277,6 +277,36 @@ def test_full_size_frame_of_the_headline_configuration(ctx, organisation):
         assert np.array_equal(rng2.download(), st)
 
 
+def test_scatter_job_of_configs4_equals_the_oracle(ctx):
+    """BASELINE.json configs[4] as SURVEY §8(d) states it ("Config 5"): 10 368 000 = 1920 x 1080 x 5 (pixel, epoch) samples of
+    distributed_ray_trace (main.rs:521-614, loop 1129-1161) from freshly seeded streams, depth 8, in ONE call of the default
+    organisation — the job bench.py times as `scatter_pass`.  Every sample, every filter flag, every generator record (516 words
+    per pixel after five epochs) and the cast count against the oracle; and the accumulated image against the oracle's sum."""
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame.full(1920, 1080, 8)
+    epochs = 5
+    assert frame.rows * frame.cols * epochs == 10_368_000
+    rng = rt.Rng(frame)
+    samples = torch.empty((epochs, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    valid = torch.empty((epochs, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, samples=samples, valid=valid, ray_count=count)
+    torch.cuda.synchronize()
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, epochs)
+    s, v = samples.cpu().numpy(), valid.cpu().numpy()
+    assert np.array_equal(v, wv) and int(count.item()) == wcasts
+    assert ((s.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(s) & np.isnan(ws))).all()
+    assert np.array_equal(rng.download(), st)
+    want = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+    for e in range(epochs):  # main.rs:1157-1167: the filter, then img += photon, epoch by epoch
+        want += np.where(wv[e][..., None] != 0, ws[e], np.float32(0))
+    assert np.array_equal(accum.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("refuse", ["1", "3", "99"])
 def test_workspace_that_cannot_be_allocated_means_smaller_batches_then_one_kernel(ctx, organisation, refuse):
     """No device memory for the batch the cap allows: the batch is halved until it fits; not even one epoch fits: the
