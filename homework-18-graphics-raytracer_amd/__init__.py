@@ -338,6 +338,13 @@ def post_process(img: np.ndarray) -> float:
     return float(_capi.host_lib().rt_post_process(img.ctypes.data_as(C.c_void_p), img.size // 3))
 
 
+def luma_row() -> tuple:
+    """The three f32 luma weights of post_process: luma = (w0 * r + w1 * g) + w2 * b."""
+    row = (C.c_float * 3)()
+    _capi.host_lib().rt_luma_row(row)
+    return (float(row[0]), float(row[1]), float(row[2]))
+
+
 def encode_srgb8(img: np.ndarray) -> np.ndarray:
     """Linear f32 -> sRGB u8, src/image.rs:55-66."""
     assert img.dtype == np.float32 and img.flags.c_contiguous

@@ -131,7 +131,7 @@ AMD_SYMBOLS = [
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
     "rt_world_push_light", "rt_world_push_flat_triangle", "rt_world_push_square", "rt_world_load_obj",
-    "rt_world_build_reference_scene", "rt_world_save_scene", "rt_world_load_scene", "rt_reference_camera", "rt_world_desc", "rt_frame_full", "rt_post_process",
+    "rt_world_build_reference_scene", "rt_world_save_scene", "rt_world_load_scene", "rt_reference_camera", "rt_world_desc", "rt_frame_full", "rt_post_process", "rt_luma_row",
     "rt_encode_srgb8", "rt_accumulate", "rt_accumulator_resolve", "rt_write_png", "rt_host_last_error",
 ]
 

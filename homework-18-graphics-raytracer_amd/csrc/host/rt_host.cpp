@@ -470,6 +470,12 @@ void rt_frame_full(uint32_t width, uint32_t height, int32_t max_depth, rt_frame 
 
 /* ---- post_process / encode / PNG ------------------------------------------ */
 
+/* the luma weights post_process uses (palette's LinSrgb::into_luma: the Y row of its rgb -> xyz matrix): for callers that take the
+ * percentile themselves (dist.post_process_sharded: the p99 of a frame whose rows live on several ranks) */
+void rt_luma_row(float *row3) {
+    if (row3) rt::luma_row(row3);
+}
+
 /* main.rs:748-762 */
 float rt_post_process(float *rgb, size_t n_pixels) {
     if (!rgb || n_pixels == 0) return 0.0f;

@@ -459,6 +459,16 @@ struct PairLds {
     float4 heads[64][2];        /* the current leaf's DevTriHead records (a leaf tested pair-wise has 64 triangles at most) */
     float4 kept[64];            /* per ray: n.d and the three signed areas of the pair that holds its key (what finish_hit needs of the winner) */
 };
+/* the same without the leaf's plane records: the passes then fetch them from global memory (the L1 holds them), for kernels whose
+ * LDS budget decides their occupancy */
+struct PairLdsSlim {
+    unsigned long long key[64];
+    uint32_t rank_lane[64];
+    uint2 cand[RT_PAIR_CANDIDATES];
+    float4 kept[64];
+};
+template <class P> struct pair_lds_has_heads { static constexpr bool value = false; };
+template <> struct pair_lds_has_heads<PairLds> { static constexpr bool value = true; };
 #ifndef RT_PAIR_MAX_NEED
 #define RT_PAIR_MAX_NEED 24u /* a clustered leaf that more lanes than this need is run wave-uniformly */
 #endif
@@ -472,7 +482,8 @@ __device__ __forceinline__ void pair_sync() { /* LDS written by some lanes of th
 
 /* The signed areas (main.rs:218-224) for the first `count` entries of the candidate list, one per lane; a pair that passes
  * puts its key on its ray's slot.  Returns whether a NaN distance was accepted. */
-__device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray, PairLds *pl, const uint32_t lane, const uint32_t count) {
+template <class PairScratch>
+__device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray, PairScratch *pl, const uint32_t lane, const uint32_t count) {
     const bool mine = lane < count;
     const uint2 c = pl->cand[lane];
     const uint32_t owner = c.y & 63u, tri = mine ? c.y >> 6 : 0u;
@@ -520,7 +531,8 @@ static __device__ unsigned long long g_pair_time[16];
 #else
 #define RT_PAIR_TIME_ARG
 #endif
-__device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ray &ray, const bool active, PairLds *pl RT_PAIR_TIME_ARG) {
+template <class PairScratch>
+__device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ray &ray, const bool active, PairScratch *pl RT_PAIR_TIME_ARG) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const CastMasks m = cast_masks(ray, sc.filter_origin2);
     /* the ray's lane predicates as bits, to travel with it: excluded triangle (or none) | keep_back keep_front ex_if_back ex_if_front filter_ok */
@@ -616,10 +628,10 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
             /* pair-wise: the leaf's plane records into LDS (one per lane), the needing lanes in lane order, then the passes */
             const uint32_t ck = pair_word & 0xffu, K = (pair_word >> 8) & 0xffu, R = pair_word >> 16;
             const uint32_t mck = pair_mck, mk = pair_mk;
-            {
+            if (need) pl->rank_lane[__builtin_amdgcn_mbcnt_hi((uint32_t)(needing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needing, 0u))] = lane;
+            if constexpr (pair_lds_has_heads<PairScratch>::value) {
                 const float4 *h = reinterpret_cast<const float4 *>(sc.heads + g_first + (lane < g_count ? lane : 0u));
                 const float4 ha = h[0], hb = h[1];
-                if (need) pl->rank_lane[__builtin_amdgcn_mbcnt_hi((uint32_t)(needing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needing, 0u))] = lane;
                 pl->heads[lane][0] = ha;
                 pl->heads[lane][1] = hb;
             }
@@ -640,7 +652,15 @@ __device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ra
                 const uint32_t local = chunk * ck + in_chunk;
                 const bool pair = slot < R && sub < n_sub && local < g_count;
                 const uint32_t owner = pl->rank_lane[rank & 63u] & 63u;
-                const float4 ha = pl->heads[local & 63u][0], hb = pl->heads[local & 63u][1];
+                float4 ha, hb;
+                if constexpr (pair_lds_has_heads<PairScratch>::value) {
+                    ha = pl->heads[local & 63u][0];
+                    hb = pl->heads[local & 63u][1];
+                } else {
+                    const float4 *h = reinterpret_cast<const float4 *>(sc.heads + g_first + (pair ? local : 0u));
+                    ha = h[0];
+                    hb = h[1];
+                }
                 const uint32_t tri = g_first + local;
                 const int from = (int)(owner << 2);
                 const V3 o = v3(pair_fetch(from, ray.o.x), pair_fetch(from, ray.o.y), pair_fetch(from, ray.o.z));

@@ -1335,8 +1335,8 @@ int distributed_chainq_workgroups_per_cu(void) {
 __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
 #ifndef RT_DIST_SHADE_NO_PAIRS
-    __shared__ PairLds pair_lds_all[RT_DIST_SHADE_THREADS / 64u];
-    PairLds *const pair_lds = &pair_lds_all[threadIdx.x >> 6];
+    __shared__ PairLdsSlim pair_lds_all[RT_DIST_SHADE_THREADS / 64u];
+    PairLdsSlim *const pair_lds = &pair_lds_all[threadIdx.x >> 6];
 #endif
     uint32_t *const bucket_start = shade_lds + 1u, *const bucket_cursor = bucket_start + DIST_SHADE_BUCKETS;
     uint32_t *const unsorted = shade_lds + DIST_SHADE_HDR;       /* slot << 24 | bucket << 16 | sample - tile0 */

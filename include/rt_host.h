@@ -80,6 +80,8 @@ void rt_frame_full(uint32_t width, uint32_t height, int32_t max_depth, rt_frame 
  * panics there, main.rs:754; this returns instead) or the percentile is
  * <= f32::EPSILON (image left untouched, main.rs:755). */
 float rt_post_process(float *rgb, size_t n_pixels);
+/* its luma weights: luma = (row3[0] * r + row3[1] * g) + row3[2] * b (palette 0.4, LinSrgb::into_luma via main.rs:750) */
+void rt_luma_row(float *row3);
 
 /* Linear f32 -> sRGB-encoded u8 (n_values = 3 * pixels). */
 void rt_encode_srgb8(const float *rgb, size_t n_values, uint8_t *out);

@@ -162,6 +162,66 @@ def test_sharded_distributed_pass_equals_single_process(tmp_path):
     assert np.array_equal(np.load(out).view(np.uint32), want.view(np.uint32))
 
 
+def _finish_worker(rank, world, port, w, h, depth, epochs, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+    import _oracle
+
+    wd, cam = rt.reference_world(), rt.reference_camera()
+    fr = rtdist.shard_frame(w, h, depth, rank, world)
+    img, _ = _oracle.render_whitted(wd.desc(), cam, fr, threads=2)
+    band = torch.from_numpy(img)
+    frames, divisors = [], []
+    u8, d = rtdist.finish_frame_sharded(band, h, rank, world)  # main.rs:1113-1114
+    frames.append(u8)
+    divisors.append(d)
+    st = _oracle.rng_init(fr)
+    for _ in range(epochs):  # main.rs:1129-1172: an epoch into the normalised image, normalise again, write
+        s, v, _c = _oracle.render_distributed(wd.desc(), cam, fr, st, 1, threads=2)
+        band += torch.from_numpy(np.where(v[0][..., None] != 0, s[0], np.float32(0)))
+        u8, d = rtdist.finish_frame_sharded(band, h, rank, world)
+        frames.append(u8)
+        divisors.append(d)
+    if rank == 0:
+        np.save(out_path, np.stack([f.numpy() for f in frames]))
+        np.save(out_path + ".div.npy", np.array(divisors, dtype=np.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 48, 36), (3, 40, 31)])
+def test_post_process_over_a_sharded_frame_is_the_reference_loop(tmp_path, world, w, h):
+    """dist.post_process_sharded / finish_frame_sharded: the p99 luma of a frame that is never assembled as f32 (a radix select
+    whose histograms are summed over the ranks), each band normalised and sRGB-encoded where it lives, u8 rows gathered — against
+    the oracle's post_process + encode of the full frame, through main()'s progressive loop (the image is renormalised in place
+    after every epoch, main.rs:1171)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import homework_18_graphics_raytracer_amd as rt
+    import _oracle
+
+    depth, epochs = 5, 2
+    out = str(tmp_path / "u8.npy")
+    mp.spawn(_finish_worker, args=(world, _free_port(), w, h, depth, epochs, out), nprocs=world, join=True)
+    got, got_div = np.load(out), np.load(out + ".div.npy")
+    wd, cam, frame = rt.reference_world(), rt.reference_camera(), rt.Frame.full(w, h, depth)
+    img, _ = _oracle.render_whitted(wd.desc(), cam, frame)
+    want_div = [_oracle.post_process(img)]
+    want = [_oracle.encode_srgb8(img)]
+    st = _oracle.rng_init(frame)
+    for _ in range(epochs):
+        s, v, _c = _oracle.render_distributed(wd.desc(), cam, frame, st, 1)
+        img += np.where(v[0][..., None] != 0, s[0], np.float32(0))
+        want_div.append(_oracle.post_process(img))
+        want.append(_oracle.encode_srgb8(img))
+    assert np.array_equal(got, np.stack(want))
+    assert np.array_equal(got_div.view(np.uint32), np.array(want_div, dtype=np.float32).view(np.uint32))
+
+
 def test_shard_arithmetic():
     import homework_18_graphics_raytracer_amd as rt
     from homework_18_graphics_raytracer_amd import dist as rtdist

@@ -84,3 +84,46 @@ def test_sharded_stochastic_pass_over_rccl_single_rank():
             assert np.array_equal(band.view(np.uint32), want[r::3].view(np.uint32)), f"band {r}"
     finally:
         dist.destroy_process_group()
+
+
+def test_post_process_sharded_over_rccl_and_the_reference_pins():
+    """dist.finish_frame_sharded on the GPU over RCCL (one rank): main()'s progressive loop with the p99 luma taken by the
+    cross-rank radix select, each band normalised and encoded on the device, u8 rows gathered — (i) bit-identical to the
+    single-device pipeline (rt_post_process_device + rt_encode_srgb8_device) after every epoch, and (ii) at 7 epochs the
+    reference's own report/out.png, to the bar of tests/test_gpu_reference_pins.py (max |diff| 1, >= 99.999 % identical)."""
+    import torch
+    import torch.distributed as dist
+    from PIL import Image
+    from pathlib import Path
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        world = rt.reference_world(); cam = rt.reference_camera(); scene = rt.Scene(world)
+        w, h, depth = 1280, 960, 5  # main.rs:1084-1085, 1098
+        frame = rtdist.shard_frame(w, h, depth, 0, 1)
+        img = rt.render_whitted(scene, cam, frame)
+        ref = img.clone()
+        u8, d = rtdist.finish_frame_sharded(img, h, 0, 1)
+        rt.post_process_device(ref)
+        assert torch.equal(img.view(torch.int32), ref.view(torch.int32)) and torch.equal(u8, rt.encode_srgb8_device(ref))
+        rng, rng_ref = rt.Rng(frame), rt.Rng(frame)
+        for k in range(1, 8):
+            rt.render_distributed(scene, cam, frame, rng, 1, focus=3.0, blur=0.04, accum=img)
+            rt.render_distributed(scene, cam, frame, rng_ref, 1, focus=3.0, blur=0.04, accum=ref)
+            u8, d = rtdist.finish_frame_sharded(img, h, 0, 1)
+            rt.post_process_device(ref)
+            assert d > 0.0 and torch.equal(img.view(torch.int32), ref.view(torch.int32)), f"epoch {k}"
+        torch.cuda.synchronize()
+        assert torch.equal(u8, rt.encode_srgb8_device(ref))
+        want = np.asarray(Image.open(Path(__file__).parent / "golden" / "ref_out_distributed.png").convert("RGB")).astype(np.int32)
+        got = u8.cpu().numpy().astype(np.int32)
+        assert got.shape == want.shape
+        diff = np.abs(got - want)
+        assert diff.max() <= 1 and np.mean(diff == 0) >= 0.99999, (diff.max(), float(np.mean(diff == 0)))
+    finally:
+        dist.destroy_process_group()
