@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
             const uint4 a = r[0], b = r[1];
             const V3 pos = v3(duf(a.x), duf(a.y), duf(a.z)), normal = v3(duf(b.x), duf(b.y), duf(b.z));
             for (uint32_t l = 0; l < key_lights; ++l) {
-                const rt_light &L = sc.lights[l];
+                const auto &L = uniform_ref(sc.lights + l);
                 const V3 toward = L.kind == RT_LIGHT_DIRECTIONAL ? v3(L.direction[0], L.direction[1], L.direction[2])
                                                                  : pos - v3(L.origin[0], L.origin[1], L.origin[2]);
                 if (dot(toward, normal) < 0.0f) key |= 1u << l;
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
         const V3 adj_n = adjust_normal(m.normal, normal); /* main.rs:410 */
         V3 sum = v3(0.0f, 0.0f, 0.0f);
         for (uint32_t light_i = 0; light_i < sc.n_lights; ++light_i) { /* wave-uniform */
-            const rt_light &L = sc.lights[light_i];
+            const auto &L = uniform_ref(sc.lights + light_i);
             DirLight dl;
             dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
             bool need = false;

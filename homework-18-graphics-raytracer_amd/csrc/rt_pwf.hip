@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     __shared__ uint4 lds_shade[PA_LQ * PA_LDS_PAGES * PA_SHADE_U4 * 64u];
     __shared__ uint4 lds_refr[PA_LDS_F_PAGES * 3u * 64u];
     __shared__ uint4 lds_node[PA_LDS_N_PAGES * 3u * 64u];
-    const KernelFrame &fr = *pp.frame;
+    const auto &fr = uniform_ref(pp.frame); /* written by the launch before this one, read-only here: scalar loads */
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_slots = fr.cols * fr.rows;
     const uint32_t n_tiles = fr.n_chunks;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
                 sdiffuse = v3(puf(e.x), puf(e.y), puf(e.z));
                 /* always true for a queued item: its light asks for a cast */
-                if (one_light) do_cast = approximate_into_directional(sc.lights[lq], spos, &dl);
+                if (one_light) do_cast = approximate_into_directional(uniform_ref(sc.lights + lq), spos, &dl);
                 else do_cast = next_shadow_ray(sc, &light_i, spos, adj_n, &dl);
                 req.o = spos;
                 req.d = -dl.direction;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 if (do_cast) {
                     bool lit = true;
                     if (cr.prim >= 0) {
-                        auto occluded = [&](const rt_light &L) {
+                        auto occluded = [&](const auto &L) {
                             const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
                             if (!has_origin) return true;
                             const V3 occ = req.o + req.d * cr.t;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                             const float light_distance = distance(spos, v3(L.origin[0], L.origin[1], L.origin[2]));
                             return occlusion_distance < light_distance;
                         };
-                        lit = one_light ? !occluded(sc.lights[lq]) : !occluded(sc.lights[light_i]);
+                        lit = one_light ? !occluded(uniform_ref(sc.lights + lq)) : !occluded(sc.lights[light_i]);
                     }
                     if (lit) { /* main.rs:450-461 */
                         Mat m;

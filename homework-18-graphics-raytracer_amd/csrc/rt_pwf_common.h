@@ -36,7 +36,8 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t *counter, bool want) {
     return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ void pw_slot_to_pixel(const KernelFrame &fr, uint32_t slot, uint32_t *row, uint32_t *col) {
+template <class Frame>
+__device__ __forceinline__ void pw_slot_to_pixel(const Frame &fr, uint32_t slot, uint32_t *row, uint32_t *col) {
     const uint32_t band_slots = fr.cols << 3;
     const uint32_t band = slot / band_slots;
     const uint32_t r = slot - band * band_slots;
@@ -193,7 +194,7 @@ __device__ __forceinline__ bool next_shadow_ray_in_step(const KernelScene &sc, u
     for (uint32_t li = first; li < sc.n_lights; ++li) {
         if (__builtin_amdgcn_ballot_w64(searching) == 0ull) break;
         DirLight dl;
-        const bool asks = approximate_into_directional(sc.lights[li], pos, &dl) && !(-dot(dl.direction, adj_n) <= 0.0f);
+        const bool asks = approximate_into_directional(uniform_ref(sc.lights + li), pos, &dl) && !(-dot(dl.direction, adj_n) <= 0.0f);
         if (searching && asks) {
             *light_i = li;
             found = true;

@@ -151,7 +151,8 @@ struct DirLight {
 };
 
 /* lights.rs:48-93.  Returns false for None (outside the spot cone). */
-RT_HD bool approximate_into_directional(const rt_light &l, V3 position, DirLight *out) {
+template <class Light> /* rt_light, or the same record in the constant address space (rt_cast.h uniform_ref: a wave-uniform light index) */
+RT_HD bool approximate_into_directional(const Light &l, V3 position, DirLight *out) {
     const V3 color = v3(l.color[0], l.color[1], l.color[2]);
     if (l.kind == RT_LIGHT_DIRECTIONAL) {
         out->direction = v3(l.direction[0], l.direction[1], l.direction[2]);
