@@ -104,22 +104,25 @@ namespace rt {
  * fields were stored, 8 spills — was as fast as this and no faster (r02_ab15.txt). */
 #define PA_SHADE_U4 5u /* uint4s per SHADE item */
 #ifndef PA_LDS_PAGES
-#define PA_LDS_PAGES 4u /* pages of SHADE items held in LDS PER QUEUE (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
+#define PA_LDS_PAGES 2u /* pages of SHADE items held in LDS PER QUEUE (a power of two; 5 KB each); what does not fit goes to the ring in the arena */
 #endif
 #ifndef PA_LQ
-#define PA_LQ 1u /* SHADE queues in LDS, by the light the item asks next: 0, 1, ..., and PA_LQ - 1 or beyond.  A chunk from one of
+#define PA_LQ 3u /* SHADE queues in LDS, by the light the item asks next: 0, 1, ..., and PA_LQ - 1 or beyond.  A chunk from one of
                   * them has ONE light (unless it is the last queue of a scene with more lights): its record comes through scalar
                   * loads and the code for its kind — a spot light's acos and powf in binary64 — runs only in chunks that need it.
                   * Measured on the reference frame (three lights): PA_LQ 3 with 2 pages per queue and 2 + 2 pages of REFR and NODE
-                  * items (the same 44 KB) executes 7 % fewer VALU instructions and is 1.5–2 % faster (1.18 against 1.20 ms) but
-                  * sends more items to the arena: 1.22 GB of HBM traffic per frame against 1.00 GB (profiles/r02_ab17…20.txt) */
+                  * items (the same 44 KB) executes 7 % fewer VALU instructions and was 1.5–2 % faster in round 2 (1.18 against 1.20 ms)
+                  * at the price of more items through the arena, 1.22 GB of HBM traffic per frame against 1.00 GB
+                  * (profiles/r02_ab17…20.txt).  Round 3, with the spill traffic gone and the kernel plainly bound by VALU issue, the
+                  * same instructions are worth 4.3 %: 1.052 against 1.100 ms (profiles/r03_ab5.txt) — the default now (PA_LQ 1 with four
+                  * pages per queue is the A/B). */
 #endif
 #define PA_LQ_SHIFT 4u /* type bits 4-5: which of them the claimed page belongs to */
 #ifndef PA_LDS_F_PAGES
-#define PA_LDS_F_PAGES 4u /* the same for REFR items (3 KB each) */
+#define PA_LDS_F_PAGES 2u /* the same for REFR items (3 KB each) */
 #endif
 #ifndef PA_LDS_N_PAGES
-#define PA_LDS_N_PAGES 4u /* and for NODE items (3 KB each: the ray, its word and contribution, the node id) */
+#define PA_LDS_N_PAGES 2u /* and for NODE items (3 KB each: the ray, its word and contribution, the node id) */
 #endif
 #define PA_IN_LDS 8u /* type bit: the claimed page is one of an LDS queue */
 #define PA_SPIN_LIMIT (1u << 22)
