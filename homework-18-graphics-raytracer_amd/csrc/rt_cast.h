@@ -49,8 +49,8 @@ struct CastResult {
 };
 
 /* World::cast, main.rs:180-326.  Convergent: `i` is wave-uniform. */
-template <bool USE_LDS>
-__device__ __forceinline__ CastResult cast(const KernelScene &sc, const DevTri *__restrict__ lds_tris, const Ray &ray) {
+template <bool USE_LDS, class Scene>
+__device__ __forceinline__ CastResult cast(const Scene &sc, const DevTri *__restrict__ lds_tris, const Ray &ray) {
     CastResult best;
     best.prim = -1;
     best.t = 0.0f;
@@ -317,7 +317,8 @@ __device__ __forceinline__ bool node_steep(const NodeRec &g, const Ray &ray) {
 
 /* Everything of World::cast after the triangle loop: the winner's backface flag and signed areas, then the
  * sphere loop (main.rs:264-324), starting from the triangles' nearest hit. */
-__device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const Ray &ray, float best_t, int32_t best_prim,
+template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
+__device__ __forceinline__ CastResult cast_finish(const Scene &sc, const Ray &ray, float best_t, int32_t best_prim,
                                                   const TriBest *kept = nullptr) {
     const uint32_t nt = sc.n_triangles;
     const bool ex_some = (ray.excl >> 31) != 0u;
@@ -372,7 +373,8 @@ __device__ __forceinline__ CastResult cast_finish(const KernelScene &sc, const R
     return best;
 }
 
-__device__ __forceinline__ CastResult cast_asm(const KernelScene &sc, const Ray &ray) {
+template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
+__device__ __forceinline__ CastResult cast_asm(const Scene &sc, const Ray &ray) {
     const CastMasks m = cast_masks(ray, sc.filter_origin2);
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     TriBest best;
@@ -482,8 +484,8 @@ __device__ __forceinline__ void pair_sync() { /* LDS written by some lanes of th
 
 /* The signed areas (main.rs:218-224) for the first `count` entries of the candidate list, one per lane; a pair that passes
  * puts its key on its ray's slot.  Returns whether a NaN distance was accepted. */
-template <class PairScratch>
-__device__ __forceinline__ bool pair_areas(const KernelScene &sc, const Ray &ray, PairScratch *pl, const uint32_t lane, const uint32_t count) {
+template <class Scene, class PairScratch>
+__device__ __forceinline__ bool pair_areas(const Scene &sc, const Ray &ray, PairScratch *pl, const uint32_t lane, const uint32_t count) {
     const bool mine = lane < count;
     const uint2 c = pl->cand[lane];
     const uint32_t owner = c.y & 63u, tri = mine ? c.y >> 6 : 0u;
@@ -531,8 +533,8 @@ static __device__ unsigned long long g_pair_time[16];
 #else
 #define RT_PAIR_TIME_ARG
 #endif
-template <class PairScratch>
-__device__ __forceinline__ CastResult cast_pairs(const KernelScene &sc, const Ray &ray, const bool active, PairScratch *pl RT_PAIR_TIME_ARG) {
+template <class Scene, class PairScratch>
+__device__ __forceinline__ CastResult cast_pairs(const Scene &sc, const Ray &ray, const bool active, PairScratch *pl RT_PAIR_TIME_ARG) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const CastMasks m = cast_masks(ray, sc.filter_origin2);
     /* the ray's lane predicates as bits, to travel with it: excluded triangle (or none) | keep_back keep_front ex_if_back ex_if_front filter_ok */
@@ -761,7 +763,8 @@ struct HitGeom {
 
 /* The tail of the accept branches of World::cast (main.rs:235-252, 304-313),
  * evaluated once for the winning primitive instead of on every improvement. */
-__device__ __forceinline__ HitGeom finish_hit(const KernelScene &sc, const Ray &ray, const CastResult &r, bool want_sphere_uv_always) {
+template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
+__device__ __forceinline__ HitGeom finish_hit(const Scene &sc, const Ray &ray, const CastResult &r, bool want_sphere_uv_always) {
     HitGeom h;
     h.prim = (uint32_t)r.prim;
     h.bf = r.bf;

@@ -176,7 +176,8 @@ __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, 
 
 /* get_shade's `for light in &self.lights` up to the next shadow cast (main.rs:413-433): advance *light_i to the first
  * light from *light_i on that needs one; false when the loop is over */
-__device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t *light_i, V3 pos, V3 adj_n, DirLight *dl) {
+template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
+__device__ __forceinline__ bool next_shadow_ray(const Scene &sc, uint32_t *light_i, V3 pos, V3 adj_n, DirLight *dl) {
     while (*light_i < sc.n_lights) {
         if (approximate_into_directional(sc.lights[*light_i], pos, dl)) {
             const float cosine = -dot(dl->direction, adj_n);
@@ -189,7 +190,8 @@ __device__ __forceinline__ bool next_shadow_ray(const KernelScene &sc, uint32_t 
 
 /* all lanes.  The same search with the wave in step: every lane that is still `searching` asks light `first`, then first + 1,
  * ... (first is wave-uniform, so each light's record comes through scalar loads and only the code for its kind runs) */
-__device__ __forceinline__ bool next_shadow_ray_in_step(const KernelScene &sc, uint32_t first, bool searching, uint32_t *light_i, V3 pos, V3 adj_n) {
+template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
+__device__ __forceinline__ bool next_shadow_ray_in_step(const Scene &sc, uint32_t first, bool searching, uint32_t *light_i, V3 pos, V3 adj_n) {
     bool found = false;
     for (uint32_t li = first; li < sc.n_lights; ++li) {
         if (__builtin_amdgcn_ballot_w64(searching) == 0ull) break;
