@@ -18,5 +18,18 @@ cd $R
 { echo "# rocprofv3 --pmc (separate passes), bench.py --steps 5 --warmup 1, 1920x1080 depth 8: mean over the dispatches of rt::pwf_kernel; FETCH_SIZE / WRITE_SIZE in KB"; python3 tools/pmc_summary.py $O/${TAG}_pmc --kernel pwf_kernel; } > $O/${TAG}_pwf_pmc.txt
 { echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 64 --calls 1 (configs[3]: 64 epochs from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB"
   for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_dist --kernel $k; done; } > $O/${TAG}_dist_pmc.txt
+cd /tmp
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_scatter/$grp -- python3 $R/tools/bench_distributed.py --epochs 5 --calls 1 > $O/${TAG}_pmc_scatter.$grp.log 2>&1
+done
+cd $R
+{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 5 --calls 1 (configs[4]: 5 epochs from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; KB"
+  for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_scatter --kernel $k; done; } > $O/${TAG}_scatter_pmc.txt
+rm -rf $O/${TAG}_pmc_scatter $O/${TAG}_pmc_scatter.*.log
+if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_need.so ]; then python3 tools/diag_need.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lane_tests_needed.txt; fi
+if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_ptime.so ]; then python3 tools/diag_pair_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chain_step_time.txt; fi
+python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 2>&1 | grep -v amdgpu.ids > $O/${TAG}_whitted_vs_r02.txt
+python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 --world 8 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_whitted_vs_r02.txt
+for lib in main nopairs r02; do arg=""; if [ "$lib" != main ]; then arg="--lib $lib"; fi; echo "$lib $(python3 tools/bench_distributed.py --epochs 8 --calls 3 --burn 32 $arg 2>/dev/null | tail -1)"; done > $O/${TAG}_stochastic_vs_r02.txt
 if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_pastats.so ]; then python3 tools/diag_pwf.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pwf_phases.txt; fi
 rm -rf $O/${TAG}_stats $O/${TAG}_pmc $O/${TAG}_pmc_dist $O/${TAG}_pmc.*.log $O/${TAG}_pmc_dist.*.log
