@@ -1332,6 +1332,17 @@ int distributed_chainq_workgroups_per_cu(void) {
 #ifndef RT_DIST_SHADE_THREADS
 #define RT_DIST_SHADE_THREADS 256
 #endif
+#ifdef RT_DIAG_PAIR_TIME
+static __device__ unsigned long long g_shade_time[8]; /* wave ticks: [0] list building + sort, [1] request load + material, [2] lights -> directional + facing, [3] the cast, [4] diffuse / specular, [5] the kernel, [6] wave-casts */
+extern "C" int rt_diag_read_shade_time(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_shade_time), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_shade_time), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#define RT_SHADE_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); sdt[k] += now_ - stick; stick = now_; }
+#else
+#define RT_SHADE_TICK(k)
+#endif
 __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) void dist_shade_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t tile, const uint32_t list_cap, const uint32_t sort) {
     extern __shared__ uint32_t shade_lds[];
 #ifndef RT_DIST_SHADE_NO_PAIRS
@@ -1343,6 +1354,11 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
     uint32_t *const shade_list = unsorted + list_cap;            /* the same, bucket by bucket */
     const uint32_t lane = threadIdx.x & 63u;
     const size_t tile0 = (size_t)blockIdx.x * tile;
+#ifdef RT_DIAG_PAIR_TIME
+    unsigned long long sdt[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long stick = __builtin_readcyclecounter();
+    const unsigned long long stick0 = stick;
+#endif
     for (uint32_t k = threadIdx.x; k < DIST_SHADE_HDR; k += blockDim.x) shade_lds[k] = 0u;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
@@ -1388,6 +1404,7 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
     }
     __syncthreads();
     uint32_t casts = 0u;
+    RT_SHADE_TICK(0)
     for (uint32_t first = (threadIdx.x >> 6) * 64u; first < total; first += blockDim.x) {
         const bool active = first + lane < total;
         V3 pos = v3(0.0f, 0.0f, 0.0f), normal = v3(0.0f, 0.0f, 1.0f), view = v3(0.0f, 0.0f, 1.0f);
@@ -1407,6 +1424,7 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
         const Mat m = material_approx(sc.materials[obj], u, v);
         const V3 adj_n = adjust_normal(m.normal, normal); /* main.rs:410 */
         V3 sum = v3(0.0f, 0.0f, 0.0f);
+        RT_SHADE_TICK(1)
         for (uint32_t light_i = 0; light_i < sc.n_lights; ++light_i) { /* wave-uniform */
             const auto &L = uniform_ref(sc.lights + light_i);
             DirLight dl;
@@ -1416,6 +1434,7 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
                 const float cosine = -dot(dl.direction, adj_n);
                 need = !(cosine <= 0.0f);
             }
+            RT_SHADE_TICK(2)
             if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
             Ray req;
             req.o = pos;
@@ -1429,6 +1448,10 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
             cr.bf = 0u;
             cr.a0 = cr.a1 = cr.a2 = 0.0f;
             if (need) cr = cast_asm(sc, req);
+#ifdef RT_DIAG_PAIR_TIME
+            RT_SHADE_TICK(3)
+            sdt[6] += 1ull;
+#endif
 #elif defined(RT_DIAG_PAIR_TIME)
             unsigned long long diag_dt[9];
             const CastResult cr = cast_pairs(sc, req, need, pair_lds, diag_dt);
@@ -1454,9 +1477,14 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
                     sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness;
                 }
             }
+            RT_SHADE_TICK(4)
         }
         if (active) dp.sp_shade[at] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     }
+#ifdef RT_DIAG_PAIR_TIME
+    sdt[5] = __builtin_readcyclecounter() - stick0;
+    if (lane == 0u) for (int q = 0; q < 7; ++q) atomicAdd(&g_shade_time[q], sdt[q]);
+#endif
     if (dp.ray_count != nullptr) {
         for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
         if (lane == 0u && casts != 0u) atomicAdd(dp.ray_count, (unsigned long long)casts);

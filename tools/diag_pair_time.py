@@ -51,3 +51,12 @@ if buf[9] or buf[10]:
     step = {9: "fetching work + shoot_focus", 10: "the hit + the level's factor", 12: "the level's draws + scatter_hit | get_refract's exit", 13: "the rest"}
     print("  outside the cast: " + ", ".join(f"{step[k]} {100.0 * buf[k] / max(total, 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in (9, 10, 12, 13)))
 print("  of the cast: " + ", ".join(f"{names[k]} {100.0 * buf[k] / max(buf[7], 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in range(1, 7)))
+
+if hasattr(lib, "rt_diag_read_shade_time"):
+    lib.rt_diag_read_shade_time.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    sb = (C.c_ulonglong * 8)()
+    assert lib.rt_diag_read_shade_time(sb, 1) == 0
+    st = max(sb[5], 1)
+    nm = ["list building + sort", "request load + material", "lights -> directional, facing", "the cast", "diffuse / specular", None, None]
+    print(f"shade kernel (all calls since the start, burn included): {sb[6]} wave-casts, {sb[3] / max(sb[6], 1):.0f} ticks per wave-cast; wave time: "
+          + ", ".join(f"{nm[k]} {100.0 * sb[k] / st:.1f} %" for k in range(5)))
