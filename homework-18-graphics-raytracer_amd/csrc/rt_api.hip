@@ -50,8 +50,6 @@ struct Workspace {
     rt::KernelFrame pw_frame;
     void *d_split = nullptr; /* split distributed pass: requests, shades and frames of one batch of epochs */
     size_t split_bytes = 0;
-    void *d_chainq = nullptr; /* queued chain kernel: one arena of item rings per resident workgroup */
-    size_t chainq_bytes = 0;
 };
 
 struct rt_scene {
@@ -72,7 +70,7 @@ static std::atomic<const uint32_t *> g_diag_tile_order{nullptr};
 #define RT_DIST_SPLIT_DEFAULT 1
 #endif
 static std::atomic<int> g_dist_split{-1}; /* -1: RT_AMD_DIST_SPLIT or the default */
-extern "C" int rt_set_distributed_split(int on) { g_dist_split.store(on < 0 ? -1 : (on > 2 ? 2 : on)); return 0; }
+extern "C" int rt_set_distributed_split(int on) { g_dist_split.store(on < 0 ? -1 : (on > 1 ? 1 : on)); return 0; } /* 2 (round 2's queued chain) is 1 now */
 extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order.store(static_cast<const uint32_t *>(device_ptr)); }
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
@@ -680,7 +678,6 @@ int rt_scene_destroy(rt_scene *scene) {
         if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
         if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
         if (kv.second.d_split) (void)hipFree(kv.second.d_split);
-        if (kv.second.d_chainq) (void)hipFree(kv.second.d_chainq);
     }
     if (scene->d_blob) e = hipFree(scene->d_blob);
     delete scene;
@@ -1112,30 +1109,6 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             }
             dp.work_queue = ws.d_counters;
             base = static_cast<char *>(ws.d_split);
-            /* the queued chain kernel's arenas (organisation 2); without them the persistent-lane chain kernel runs */
-            dp.cq_arena = nullptr;
-            dp.cq_arena_stride = 0;
-            dp.cq_groups = 0u;
-            if (split == 2 && base != nullptr) {
-                const uint32_t groups = rng->compute_units * (uint32_t)rt::distributed_chainq_workgroups_per_cu();
-                const size_t stride = (rt::distributed_chainq_arena_bytes() + 255u) & ~(size_t)255u;
-                const size_t need_q = (size_t)groups * stride;
-                if (ws.chainq_bytes < need_q) {
-                    if (ws.d_chainq) {
-                        RT_HIP(hipStreamSynchronize(stream));
-                        (void)hipFree(ws.d_chainq);
-                        ws.d_chainq = nullptr;
-                        ws.chainq_bytes = 0;
-                    }
-                    if (hipMalloc(&ws.d_chainq, need_q) == hipSuccess) ws.chainq_bytes = need_q;
-                    else { (void)hipGetLastError(); ws.d_chainq = nullptr; }
-                }
-                if (ws.d_chainq != nullptr) {
-                    dp.cq_arena = static_cast<unsigned char *>(ws.d_chainq);
-                    dp.cq_arena_stride = stride;
-                    dp.cq_groups = groups;
-                }
-            }
         }
         if (base == nullptr) goto one_kernel;
         dp.sp_hdr = reinterpret_cast<uint32_t *>(base + o_hdr);
@@ -1162,7 +1135,6 @@ one_kernel:
     dp.n_epochs = n_epochs;
     dp.epoch0 = 0;
     dp.sp_hdr = nullptr; dp.sp_req = nullptr; dp.sp_shade = nullptr; dp.sp_frame = nullptr; dp.sp_slots = 0;
-    dp.cq_arena = nullptr; dp.cq_arena_stride = 0; dp.cq_groups = 0u;
     {
         const char *v = getenv("RT_AMD_DIST_STATIC"); /* A/B: one 64-pixel chunk per wave instead of persistent lanes */
         if (!(v && *v == '1')) {

@@ -1012,309 +1012,9 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     }
 }
 
-#undef RT_STEP_TICK
-#define RT_STEP_TICK(k) /* the diagnostic ticks are the persistent-lane chain kernel's */
-
-/* ---- the chain as a kernel of workgroup-local queues ("queued chain") -----------------------------------------------
- * dist_chain_kernel keeps a lane on one pixel: after a few steps the 64 lanes of a wave sit in all phases of the chain at
- * once, so every iteration executes the code of every phase — the ziggurat draws of shoot_focus, weighted_select and
- * scatter_hit (a powf, an acos, two sincos in binary64), the refraction step, the level's factor — for a fraction of its
- * lanes each, and the primary rays (coherent: neighbouring pixels, nearly parallel) share their intersection loop with
- * scattered ones, so none of its wave-level exits fire.  Here, as in the Whitted path (rt_pwf.hip), every cast is a work
- * item: a (pixel, epoch) sample's whole state (26 dwords) is an ITEM that moves through three queues of its workgroup —
- *
- *   START  shoot_focus is due (main.rs:1144-1149), then the primary cast (1150)
- *   NEXT   the cast of a level's reflected / escape ray (main.rs:564, 583, 603), then the next level's draws
- *   REFR   a cast inside the glass: get_refract's first one or a total-internal-reflection bounce (main.rs:371, 381)
- *
- * — and a wave takes a page of 64 items of ONE queue: one phase's code per chunk, and the chunks of primary rays are
- * coherent.  A workgroup fetches 64-pixel chunks of the tile from the frame-wide counter while fewer than CQ_PIX_LIMIT of
- * its pixels are in flight; a pixel's epochs of the batch follow each other (its random stream is sequential: the item of
- * epoch e becomes the START item of epoch e + 1), then its generator is parked.  Items are field-major in pages of 64
- * (rt_pwf_common.h), queue bookkeeping and the claim / seal / sleep protocol are rt_pwf.hip's.  The per-sample arithmetic
- * and the order of a pixel's draws are those of dist_chain_kernel (rt_dist_advance.inc is included in both), so samples,
- * flags, generator records and cast counts are the same bit for bit (tests/test_gpu_distributed_parity.py). */
-#ifndef CQ_WAVES
-#define CQ_WAVES 4u
-#endif
-#define CQ_THREADS (CQ_WAVES * 64u)
-#ifndef CQ_MIN_WAVES
-#define CQ_MIN_WAVES 5
-#endif
-#define CQ_FIELDS 7u      /* uint4s per item */
-#ifndef CQ_RING
-#define CQ_RING 2048u     /* items per ring (power of two) */
-#endif
-#ifndef CQ_PIX_LIMIT
-#define CQ_PIX_LIMIT 1280u /* pixels in flight per workgroup: every one has exactly one item, queued or in a wave's registers, so a ring
-                            * never holds more than this; the rest of the ring is slack for pages still being read when the
-                            * ring comes round (at most one per wave) */
-#endif
-#ifndef CQ_SLEEP
-#define CQ_SLEEP 16
-#endif
-#ifndef CQ_MIN_PARTIAL
-#define CQ_MIN_PARTIAL 1u /* a wave with no full page to take seals a partly filled one that holds at least this many items; the last
-                           * wave awake takes anything.  1: measured 2.42 ms per epoch against 2.64 / 2.85 / 3.04 for 16 / 32 / 48 —
-                           * a sleeping wave costs more than a thin chunk (profiles/README.md, round 2) */
-#endif
-static_assert((CQ_RING & (CQ_RING - 1u)) == 0u && CQ_PIX_LIMIT + 64u * (CQ_WAVES + 2u) <= CQ_RING, "ring slack");
-/* (Tried on top of this, profiles/README.md round 2: NEXT and REFR items binned by whether their ray can meet a clustered
- * segment at all, so that the chunks of the "far" queues skip the dodecahedron's 36 triangles for the whole wave — slower,
- * 2.63 against 2.42 ms per epoch: the "near" queues hold a few per cent of the items and are taken in thin chunks.) */
-enum : uint32_t { CQ_Q_START = 0u, CQ_Q_NEXT = 1u, CQ_Q_REFR = 2u, CQ_QUEUES = 3u, CQ_T_TILE = 3u, CQ_T_NONE = 4u };
-
-struct CqShared {
-    PaQueue q[CQ_QUEUES];
-    uint32_t ready[CQ_QUEUES][CQ_RING / 64u];
-    uint32_t inflight;        /* pixels fetched and not yet through their last epoch */
-    uint32_t tiles_exhausted; /* the frame-wide counter ran out */
-    uint32_t idle, gen, done;
-};
-
-size_t distributed_chainq_arena_bytes(void) { return (size_t)CQ_QUEUES * CQ_RING * CQ_FIELDS * sizeof(uint4); }
-int distributed_chainq_workgroups_per_cu(void);
-
-__global__ __launch_bounds__(CQ_THREADS, CQ_MIN_WAVES) void dist_chainq_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
-    __shared__ CqShared S;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_slots = fr.cols * fr.rows;
-    const uint32_t band_slots = fr.cols << 3;
-    const size_t n_pixels = total_slots;
-    const size_t n_samples = n_pixels * dp.n_epochs; /* of this batch */
-    const uint32_t n_tiles = (total_slots + 63u) / 64u;
-    const V3 cam_x = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
-    const V3 cam_y = v3(fr.cam_y[0], fr.cam_y[1], fr.cam_y[2]);
-    const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
-    const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
-    uint4 *rings = reinterpret_cast<uint4 *>(dp.cq_arena + (size_t)blockIdx.x * dp.cq_arena_stride);
-    const uint32_t ring_mask = CQ_RING - 1u, page_mask = CQ_RING / 64u - 1u;
-
-    for (uint32_t i = threadIdx.x; i < CQ_QUEUES * (CQ_RING / 64u); i += CQ_THREADS) (&S.ready[0][0])[i] = 0u;
-    if (threadIdx.x == 0u) {
-        for (uint32_t k = 0; k < CQ_QUEUES; ++k) S.q[k].alloc = S.q[k].taken = 0u;
-        S.inflight = 0u;
-        S.tiles_exhausted = 0u;
-        S.idle = S.gen = S.done = 0u;
-    }
-#ifdef RT_CQ_PAIRS
-    __shared__ PairLds cq_pairs[CQ_WAVES];
-#endif
-    __syncthreads();
-    uint32_t casts = 0u;
-
-    for (;;) {
-        if (lds_load(&S.done) != 0u) break;
-        /* ---- find work (lane 0 decides, the wave follows): a full page of any queue, else a fresh chunk of pixels, else a
-         * partly filled page, else sleep until somebody publishes ---- */
-        uint32_t type = CQ_T_NONE, start = 0u, count = 0u;
-        if (lane == 0u) {
-            const uint32_t gen = lds_load(&S.gen); /* before looking: a publish during the look must not be slept through */
-            const uint32_t order[CQ_QUEUES] = {CQ_Q_NEXT, CQ_Q_REFR, CQ_Q_START};
-            for (uint32_t k = 0; k < CQ_QUEUES && type == CQ_T_NONE; ++k) {
-                count = pa_claim(&S.q[order[k]], S.ready[order[k]], page_mask, 0u, &start);
-                if (count != 0u) type = order[k];
-            }
-            if (type == CQ_T_NONE && lds_load(&S.tiles_exhausted) == 0u && lds_load(&S.inflight) + 64u <= CQ_PIX_LIMIT) {
-                const uint32_t k = atomicAdd(dp.work_queue, 1u);
-                if (k >= n_tiles) {
-                    S.tiles_exhausted = 1u;
-                } else {
-                    start = k;
-                    count = total_slots - k * 64u < 64u ? total_slots - k * 64u : 64u;
-                    atomicAdd(&S.inflight, count);
-                    type = CQ_T_TILE;
-                }
-            }
-            for (int last = 0; last < 2 && type == CQ_T_NONE; ++last) {
-                for (uint32_t k = 0; k < CQ_QUEUES && type == CQ_T_NONE; ++k) {
-                    count = pa_claim(&S.q[order[k]], S.ready[order[k]], page_mask, last ? 1u : CQ_MIN_PARTIAL, &start);
-                    if (count != 0u) type = order[k];
-                }
-                if (type != CQ_T_NONE) break;
-                if (last) {
-                    /* the last wave awake found nothing whatsoever: the queues are final (idle waves stay counted while they sleep) */
-                    if (lds_load(&S.idle) == CQ_WAVES - 1u) S.done = 1u;
-                    break;
-                }
-                if (atomicAdd(&S.idle, 1u) + 1u == CQ_WAVES) { /* everybody else sleeps: look once more, for anything */
-                    atomicSub(&S.idle, 1u);
-                    continue;
-                }
-                uint32_t spins = 0u;
-                while (lds_load(&S.gen) == gen && lds_load(&S.done) == 0u) {
-                    __builtin_amdgcn_s_sleep(CQ_SLEEP);
-                    if (++spins > (1u << 22)) S.done = 1u; /* cannot happen (nobody waits for a particular wave); a hang would cost a GPU */
-                }
-                atomicSub(&S.idle, 1u);
-                break;
-            }
-        }
-        type = (uint32_t)__builtin_amdgcn_readfirstlane((int)type);
-        start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-        count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
-        if (type == CQ_T_NONE) continue;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* the page's items were written before they were counted */
-
-        /* ---- the chunk's samples ---- */
-        const bool active = lane < count;
-        uint32_t phase = DP_DONE, epoch = 0u, out_index = 0u;
-        Ray req;
-        req.o = v3(0.0f, 0.0f, 0.0f);
-        req.d = v3(0.0f, 0.0f, 1.0f);
-        req.mode = FACE_FRONT;
-        req.excl = 0u;
-        HitGeom h;
-        h.pos = h.normal = v3(0.0f, 0.0f, 0.0f);
-        h.u = h.v = 0.0f;
-        h.prim = h.bf = h.obj = 0u;
-        V3 h_in_dir = v3(0.0f, 0.0f, 0.0f), sdir = v3(0.0f, 0.0f, 0.0f);
-        uint32_t h_in_mode = FACE_FRONT, kind = 0u;
-        int32_t sp = 0, retry = 0;
-        float travel = 0.0f;
-        if (type == CQ_T_TILE) {
-            if (active) {
-                const uint32_t slot = start * 64u + lane;
-                const uint32_t band = slot / band_slots;
-                const uint32_t r = slot - band * band_slots;
-                const uint32_t rows_left = fr.rows - (band << 3);
-                const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
-                const uint32_t col = r / band_rows;
-                const uint32_t row = (band << 3) + (r - col * band_rows);
-                out_index = row * fr.cols + col;
-                phase = DP_START;
-            }
-        } else if (active) {
-            const uint4 *t = rings + (size_t)type * CQ_RING * CQ_FIELDS + pa_entry((start + lane) & ring_mask, CQ_FIELDS);
-            const uint4 f0 = t[PA_F(0u)], f1 = t[PA_F(1u)], f6 = t[PA_F(6u)];
-            out_index = f1.w;
-            epoch = f6.x & 0xffu;
-            sp = (int32_t)((f6.x >> 8) & 0xffu);
-            kind = (f6.x >> 16) & 3u;
-            retry = (int32_t)((f6.x >> 18) & 15u);
-            req.mode = (f6.x >> 22) & 3u;
-            h_in_mode = (f6.x >> 24) & 3u;
-            h.bf = (f6.x >> 26) & 1u;
-            phase = (f6.x >> 27) & 7u;
-            h.obj = f6.y;
-            if (phase != DP_START) { /* a START item is its pixel and its epoch; the ray is made below */
-                const uint4 f2 = t[PA_F(2u)], f3 = t[PA_F(3u)], f4 = t[PA_F(4u)], f5 = t[PA_F(5u)];
-                req.o = v3(duf(f0.x), duf(f0.y), duf(f0.z));
-                req.d = v3(duf(f0.w), duf(f1.x), duf(f1.y));
-                req.excl = f1.z;
-                h.pos = v3(duf(f2.x), duf(f2.y), duf(f2.z)); h.u = duf(f2.w);
-                h.normal = v3(duf(f3.x), duf(f3.y), duf(f3.z)); h.v = duf(f3.w);
-                h_in_dir = v3(duf(f4.x), duf(f4.y), duf(f4.z)); travel = duf(f4.w);
-                sdir = v3(duf(f5.x), duf(f5.y), duf(f5.z)); h.prim = f5.w;
-            }
-        }
-        Rng rng;
-        rng.rec = rng.st = dp.rng_states;
-        rng.index = 256u;
-        rng.flags = 0u;
-        rng.lds = nullptr; /* a block that is not prepared is generated in place (rare: the look-ahead keeps one block ahead) */
-        if (active) rng_open(rng, dp.rng_states + (size_t)out_index * RNG_WORDS);
-
-        /* get_shade(&h') with h' = h seen along `view` is due: leave it to dist_shade_kernel, in request slot sp */
-        auto emit_request = [&](V3 view) {
-            const size_t s = (size_t)epoch * n_pixels + out_index;
-            uint4 *r = dp.sp_req + ((size_t)sp * n_samples + s) * 4u;
-            r[0] = make_uint4(dfu(h.pos.x), dfu(h.pos.y), dfu(h.pos.z), dfu(h.u));
-            r[1] = make_uint4(dfu(h.normal.x), dfu(h.normal.y), dfu(h.normal.z), dfu(h.v));
-            r[2] = make_uint4(dfu(view.x), dfu(view.y), dfu(view.z), h.obj);
-            r[3] = make_uint4(h.prim, 0u, 0u, 0u);
-        };
-        if (phase == DP_START) { /* Camera::shoot_focus (main.rs:101-127); wave-uniform: the chunks of START items hold nothing else */
-            const uint32_t row = out_index / fr.cols, col = out_index - row * fr.cols;
-            const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
-            const float clip_y = (fr.half_height - (float)y) / fr.height_f;
-            const float clip_x = ((float)x - fr.half_width) / fr.height_f;
-            const V3 direction = normalize(clip_x * cam_x + clip_y * cam_y + cam_t);
-            double nx, ny;
-            standard_normal_x2(rng, &nx, &ny);
-            const float xoffset = (float)(0.0 + (double)dp.blur * nx);
-            const float yoffset = (float)(0.0 + (double)dp.blur * ny);
-            req.d = normalize(direction * dp.focus + cam_x * xoffset + cam_y * yoffset);
-            req.o = cam_o - (cam_x * xoffset + cam_y * yoffset);
-            req.mode = FACE_FRONT;
-            req.excl = 0u;
-            sp = 0;
-            phase = DP_PRIMARY;
-        }
-
-        CastResult cr;
-        cr.prim = -1;
-        cr.t = 0.0f;
-        cr.bf = 0u;
-        cr.a0 = cr.a1 = cr.a2 = 0.0f;
-#ifdef RT_CQ_PAIRS /* A/B: the pair-wise cast in the queued organisation too */
-        cr = cast_pairs(sc, req, phase != DP_DONE, &cq_pairs[threadIdx.x >> 6]);
-        if (phase != DP_DONE) casts += 1u;
-#else
-        if (phase != DP_DONE) {
-            cr = cast_asm(sc, req);
-            casts += 1u;
-        }
-#endif
-
-        bool finished_pixel = false;
-        if (phase != DP_DONE) {
-#include "rt_dist_advance.inc"
-            if (!casting) { /* the chain of this (pixel, epoch) is over */
-                dp.sp_hdr[(size_t)epoch * n_pixels + out_index] = (uint32_t)sp | (terminal ? 0x100u : 0u);
-                epoch += 1u;
-                if (epoch < dp.n_epochs) {
-                    phase = DP_START;
-                } else {
-                    finished_pixel = true;
-                    phase = DP_DONE;
-                }
-            }
-            rng_park(rng); /* the stream position travels in the record: the next step may run in another wave */
-        }
-
-        /* ---- hand the samples on: each to the queue of its new phase ---- */
-        const uint32_t meta = (epoch & 0xffu) | (((uint32_t)sp & 0xffu) << 8) | ((kind & 3u) << 16) | (((uint32_t)retry & 15u) << 18) |
-                              ((req.mode & 3u) << 22) | ((h_in_mode & 3u) << 24) | ((h.bf & 1u) << 26) | ((phase & 7u) << 27);
-#pragma unroll
-        for (uint32_t qi = 0; qi < CQ_QUEUES; ++qi) {
-            const bool want = qi == CQ_Q_START ? phase == DP_START : qi == CQ_Q_NEXT ? phase == DP_NEXT : (phase == DP_REFR_INSIDE || phase == DP_REFR_BOUNCE);
-            const uint32_t pos = lds_append(&S.q[qi].alloc, want);
-            if (want) {
-                uint4 *t = rings + (size_t)qi * CQ_RING * CQ_FIELDS + pa_entry(pos & ring_mask, CQ_FIELDS);
-                t[PA_F(1u)] = make_uint4(dfu(req.d.y), dfu(req.d.z), req.excl, out_index);
-                t[PA_F(6u)] = make_uint4(meta, h.obj, 0u, 0u);
-                if (qi != CQ_Q_START) {
-                    t[PA_F(0u)] = make_uint4(dfu(req.o.x), dfu(req.o.y), dfu(req.o.z), dfu(req.d.x));
-                    t[PA_F(2u)] = make_uint4(dfu(h.pos.x), dfu(h.pos.y), dfu(h.pos.z), dfu(h.u));
-                    t[PA_F(3u)] = make_uint4(dfu(h.normal.x), dfu(h.normal.y), dfu(h.normal.z), dfu(h.v));
-                    t[PA_F(4u)] = make_uint4(dfu(h_in_dir.x), dfu(h_in_dir.y), dfu(h_in_dir.z), dfu(travel));
-                    t[PA_F(5u)] = make_uint4(dfu(sdir.x), dfu(sdir.y), dfu(sdir.z), h.prim);
-                }
-            }
-            pa_publish(S.ready[qi], page_mask, want, pos, &S.gen);
-        }
-        {
-            const unsigned long long fin = __builtin_amdgcn_ballot_w64(finished_pixel);
-            if (fin != 0ull && lane == 0u) {
-                atomicSub(&S.inflight, (uint32_t)__builtin_popcountll(fin));
-                atomicAdd(&S.gen, 1u); /* room for another chunk of pixels: wake a sleeper */
-            }
-        }
-    }
-
-    if (dp.ray_count != nullptr) {
-        uint32_t c = casts;
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-        if (lane == 0u && c != 0u) atomicAdd(dp.ray_count, (unsigned long long)c);
-    }
-}
-
-int distributed_chainq_workgroups_per_cu(void) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dist_chainq_kernel, (int)CQ_THREADS, 0) != hipSuccess || n < 1) n = 1;
-    return n;
-}
+/* (Round 2 also had the chain as a kernel of workgroup-local queues — every cast a work item, START / NEXT / REFR queues, phase-
+ * coherent chunks, the organisation of the Whitted path.  It lost to the persistent lanes above twice: 2.35 against 2.28 ms per epoch
+ * in round 2, 1 015 against 1 136 Msamples/s in round 3 with the pair-wise cast in both (profiles/README.md), and is gone.) */
 
 /* get_shade (main.rs:407-464) for every request of the batch.  The request arrays are sparse — slot k of a sample is in
  * use only if its chain got that far (90 % at slot 0, a few per cent at slot 8) — so a workgroup first lists the live
@@ -1552,13 +1252,7 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
         if (per_simd >= 1u && per_simd <= (uint32_t)RT_DIST_CHAIN_MIN_WAVES) chain_waves = resident_waves / 3u * per_simd;
     }
     if (waves > chain_waves) waves = chain_waves;
-    if (dp.cq_arena != nullptr && dp.cq_groups != 0u) {
-        uint32_t groups = (total + 63u) / 64u; /* a workgroup fetches whole 64-pixel chunks */
-        if (groups > dp.cq_groups) groups = dp.cq_groups;
-        hipLaunchKernelGGL(dist_chainq_kernel, dim3(groups), dim3(CQ_THREADS), 0, stream, sc, fr, dp);
-    } else {
-        hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
-    }
+    hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     if (after_chain != nullptr) {
         const hipError_t e = after_chain(after_chain_ctx);
         if (e != hipSuccess) return e;

@@ -127,13 +127,7 @@ struct DistParams {
     float4 *sp_shade;              /* [slot][sample]: get_shade results */
     float4 *sp_frame;              /* [level][sample]: factor.xyz, kind */
     uint32_t sp_slots;             /* max_depth + 1 */
-    /* queued chain kernel (dist_chainq_kernel): one arena of item rings per workgroup; null = the persistent-lane chain kernel */
-    unsigned char *cq_arena;
-    size_t cq_arena_stride;
-    uint32_t cq_groups;            /* resident workgroups = arenas */
 };
-size_t distributed_chainq_arena_bytes(void);
-int distributed_chainq_workgroups_per_cu(void);
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
 #define RT_RNG_DEVICE_WORDS 1032u /* the device record: two banks of it (rt_distributed.hip) */

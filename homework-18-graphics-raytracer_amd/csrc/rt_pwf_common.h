@@ -47,7 +47,7 @@ __device__ __forceinline__ void pw_slot_to_pixel(const Frame &fr, uint32_t slot,
     *row = (band << 3) + (r - *col * band_rows);
 }
 
-/* ---- workgroup-local queues of work items (used by rt_pwf.hip and by the queued chain kernel of rt_distributed.hip) ----
+/* ---- workgroup-local queues of work items (used by rt_pwf.hip) ----
  * Positions are reserved with one wave-aggregated atomic on `alloc` (lds_append), the items are written, and then counted
  * into `ready[page]` (pa_publish); consumers claim whole pages of 64 positions in order (pa_claim), full or — once nothing
  * fuller is to be had — SEALED: `alloc` is moved to the page boundary by compare-and-swap so that no reservation can slip

@@ -322,8 +322,7 @@ int rt_set_wavefront_budget(unsigned nodes_per_pixel);
  *                at most RT_AMD_DIST_WS_MB MiB, default 16384; a batch is as many epochs as fit, 16 at most, and fewer if the device
  *                cannot provide the memory — down to organisation 0 when not even one epoch fits; a workspace that holds at
  *                least half the batch wanted is kept rather than replaced);
- *   2            as 1 with the chain as a kernel of workgroup-local queues (every cast a work item, as in the Whitted path):
- *                phase-coherent chunks, 1.1 GB more workspace; measured 3 % slower than 1;
+ *   2            round 2's queued chain kernel: measured slower than 1 twice and removed in round 3 — the value now selects 1;
  *   0            one kernel, a lane stays on its pixel through chain, shades and unwind (no workspace).
  * -1 restores the default / the RT_AMD_DIST_SPLIT environment variable. */
 int rt_set_distributed_split(int on);

@@ -72,5 +72,5 @@ print(json.dumps({
     "casts_per_sample": round(casts / samples, 3), "rng_state_GB": round(pixels * 4128 / 1e9, 3),
     "rng_seed_ms": round(t_seed * 1e3, 2),
     "rng_algorithmic_bytes_per_sample_if_reloaded_every_epoch": 4128,
-    "rng_note": "two 2064 B banks per pixel stay in HBM; a visit reads the words it draws (~40 B per sample) and the look-ahead pass moves 3 KB per 256-word block (~120 B per sample); measured HBM traffic of all kernels: profiles/r01_dist_split_pmc.txt",
+    "rng_note": "two 2064 B banks per pixel stay in HBM; a visit reads the words it draws (~40 B per sample) and the look-ahead pass moves 3 KB per 256-word block (~120 B per sample); measured HBM traffic of all kernels: profiles/r03_dist_pmc.txt",
 }))
