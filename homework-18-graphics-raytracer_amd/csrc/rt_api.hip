@@ -171,6 +171,14 @@ static std::mutex g_prof_mutex;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static size_t g_prof_used = 0;
 static std::atomic<bool> g_prof_on{false};
+/* the profiling events live on the device that was current when they were made: calls that hop between devices (rt_multi_*) are
+ * not profiled (the thread-local switch is theirs) */
+static thread_local bool t_prof_off = false;
+struct ProfilingOff {
+    bool prev;
+    ProfilingOff() : prev(t_prof_off) { t_prof_off = true; }
+    ~ProfilingOff() { t_prof_off = prev; }
+};
 
 int rt_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
@@ -823,7 +831,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         qs.timeline = g_diag_timeline;
 #endif
     }
-    if (g_prof_on.load()) {
+    if (g_prof_on.load() && !t_prof_off) {
         std::lock_guard<std::mutex> lock(g_prof_mutex);
         if (g_prof_used == g_prof_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -1365,6 +1373,7 @@ int rt_multi_render_whitted_host(rt_multi *m, const rt_camera *camera, const rt_
     if (!m || !camera || !h_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_whitted_host: null argument");
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_whitted_host: bad frame");
     DeviceRestore restore;
+    ProfilingOff no_profiling;
     std::vector<rt_frame> frames;
     int rc = multi_prepare(m, frame, &frames, true);
     const int n = (int)m->parts.size();
@@ -1402,6 +1411,7 @@ int rt_multi_render_distributed_host(rt_multi *m, const rt_camera *camera, const
     if (!m || !camera || !h_accum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_distributed_host: null argument");
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_distributed_host: bad frame");
     DeviceRestore restore;
+    ProfilingOff no_profiling;
     std::vector<rt_frame> frames;
     int rc = multi_prepare(m, frame, &frames, true);
     const int n = (int)m->parts.size();
@@ -1485,6 +1495,7 @@ int rt_multi_render_whitted(rt_multi *m, const rt_camera *camera, const rt_frame
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_whitted: bad frame");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     DeviceRestore restore;
+    ProfilingOff no_profiling;
     std::vector<rt_frame> frames;
     int rc = multi_prepare(m, frame, &frames, false);
     const int n = (int)m->parts.size();
@@ -1507,6 +1518,7 @@ int rt_multi_render_distributed(rt_multi *m, const rt_camera *camera, const rt_f
     if (!frame_ok(frame)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_multi_render_distributed: bad frame");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     DeviceRestore restore;
+    ProfilingOff no_profiling;
     std::vector<rt_frame> frames;
     int rc = multi_prepare(m, frame, &frames, false);
     rc = rc == RT_OK ? multi_generators(m, frame, frames) : rc;
