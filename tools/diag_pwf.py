@@ -22,7 +22,10 @@ frame = rt.Frame.full(W, H, depth) if world_n == 1 else rt.Frame.rows_of_rank(W,
 h = C.c_void_p(); assert lib.rt_scene_create(C.byref(desc), C.byref(h)) == 0
 out = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
 lib.rt_set_variant(18)
-for _ in range(2):
+lib.rt_diag_read_pwf_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+for k in range(5):  # three untimed frames (the first touches the arenas' pages for the first time), then two counted ones
+    if k == 3:
+        assert lib.rt_diag_read_pwf_phases((C.c_ulonglong * 32)(), 1) == 0
     assert lib.rt_render_whitted(h, C.byref(cam), C.byref(frame), C.c_void_p(out.data_ptr()), None, None) == 0
     torch.cuda.synchronize()
 g = (C.c_uint32 * 32)()
@@ -36,7 +39,6 @@ h = [g[20 + k] for k in range(5)]
 print("chunks by item count (<=8, <=16, <=32, <64, 64):", h, "shares", [round(x / max(1, sum(h)), 3) for x in h])
 
 # wave time by phase (shader-clock ticks summed over all waves, both frames above; the shares are what matters)
-lib.rt_diag_read_pwf_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 ph = (C.c_ulonglong * 32)()
 assert lib.rt_diag_read_pwf_phases(ph, 1) == 0
 ph = list(ph)
