@@ -634,7 +634,19 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     const size_t off_lights = off_mats + up(desc->n_materials * sizeof(rt_material));
     const size_t off_segments = off_lights + up(desc->n_lights * sizeof(rt_light));
     const size_t off_heads = off_segments + up(segments.size() * sizeof(rt::DevSegment));
-    const size_t total = off_heads + up(heads.size() * sizeof(rt::DevTriHead)) + 256;
+    const size_t off_light_aux = off_heads + up(heads.size() * sizeof(rt::DevTriHead));
+    const size_t total = off_light_aux + up(desc->n_lights * sizeof(rt::LightAux)) + 256;
+    /* a spot light's cone edge as a cosine, with margins (rt_shade.h light_asks); anything unusual switches the shortcut off */
+    std::vector<rt::LightAux> light_aux(desc->n_lights);
+    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+        light_aux[i].cos_in = std::numeric_limits<float>::infinity();
+        light_aux[i].cos_out = -std::numeric_limits<float>::infinity();
+        const double a = (double)desc->lights[i].angle;
+        if (desc->lights[i].kind == RT_LIGHT_SPOT && a > 1e-3 && a < 3.14) {
+            light_aux[i].cos_in = std::nextafter((float)(cos(a) + 1e-4), std::numeric_limits<float>::infinity());
+            light_aux[i].cos_out = std::nextafter((float)(cos(a) - 1e-4), -std::numeric_limits<float>::infinity());
+        }
+    }
 
     std::vector<unsigned char> blob(total, 0);
     if (!tris.empty()) memcpy(&blob[off_tris], tris.data(), tris.size() * sizeof(rt::DevTri));
@@ -644,6 +656,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (desc->n_lights) memcpy(&blob[off_lights], desc->lights, desc->n_lights * sizeof(rt_light));
     if (!segments.empty()) memcpy(&blob[off_segments], segments.data(), segments.size() * sizeof(rt::DevSegment));
     if (!heads.empty()) memcpy(&blob[off_heads], heads.data(), heads.size() * sizeof(rt::DevTriHead));
+    if (!light_aux.empty()) memcpy(&blob[off_light_aux], light_aux.data(), light_aux.size() * sizeof(rt::LightAux));
 
     rt_scene *sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -669,6 +682,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.segments = reinterpret_cast<const rt::DevSegment *>(base + off_segments);
     sc->ks.n_segments = (uint32_t)segments.size();
     sc->ks.heads = reinterpret_cast<const rt::DevTriHead *>(base + off_heads);
+    sc->ks.light_aux = reinterpret_cast<const rt::LightAux *>(base + off_light_aux);
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);

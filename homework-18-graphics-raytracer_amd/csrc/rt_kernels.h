@@ -10,6 +10,7 @@
 
 #include "../../include/rt_amd.h"
 #include "rt_device_scene.h"
+#include "rt_shade.h"
 
 #ifndef RT_BLOCK_THREADS
 #define RT_BLOCK_THREADS 64 /* one wave per workgroup: a finished wave frees its slot at once (256-thread groups idled 40 % of the slots) */
@@ -48,6 +49,7 @@ struct KernelScene {
     const DevSegment *segments; /* the triangles as runs, clusters among them (rt_device_scene.h) */
     uint32_t n_segments;
     const DevTriHead *heads;    /* plane + bounding sphere per triangle, for the pair-wise tests (rt_cast.h cast_pairs) */
+    const LightAux *light_aux;  /* per light: the cosine of a spot light's spread with its margins (rt_shade.h light_asks) */
 };
 
 /* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),

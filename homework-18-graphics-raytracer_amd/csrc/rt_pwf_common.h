@@ -179,9 +179,10 @@ __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, 
 template <class Scene> /* KernelScene, by value or in the kernel-argument segment (constant address space) */
 __device__ __forceinline__ bool next_shadow_ray(const Scene &sc, uint32_t *light_i, V3 pos, V3 adj_n, DirLight *dl) {
     while (*light_i < sc.n_lights) {
-        if (approximate_into_directional(sc.lights[*light_i], pos, dl)) {
-            const float cosine = -dot(dl->direction, adj_n);
-            if (!(cosine <= 0.0f)) return true;
+        V3 direction;
+        if (light_asks(sc.lights[*light_i], sc.light_aux[*light_i], pos, adj_n, &direction)) {
+            (void)approximate_into_directional(sc.lights[*light_i], pos, dl); /* the light asks: its colour too */
+            return true;
         }
         *light_i += 1u;
     }
@@ -195,8 +196,8 @@ __device__ __forceinline__ bool next_shadow_ray_in_step(const Scene &sc, uint32_
     bool found = false;
     for (uint32_t li = first; li < sc.n_lights; ++li) {
         if (__builtin_amdgcn_ballot_w64(searching) == 0ull) break;
-        DirLight dl;
-        const bool asks = approximate_into_directional(uniform_ref(sc.lights + li), pos, &dl) && !(-dot(dl.direction, adj_n) <= 0.0f);
+        V3 direction;
+        const bool asks = light_asks(uniform_ref(sc.lights + li), uniform_ref(sc.light_aux + li), pos, adj_n, &direction);
         if (searching && asks) {
             *light_i = li;
             found = true;

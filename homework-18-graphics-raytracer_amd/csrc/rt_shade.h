@@ -180,6 +180,44 @@ RT_HD bool approximate_into_directional(const Light &l, V3 position, DirLight *o
     return true;
 }
 
+/* Does get_shade's light loop (main.rs:413-433) reach the shadow cast for this light — approximate_into_directional returns a
+ * directional AND its cosine with the adjusted normal is positive?  The same answer as the full evaluation, without a spot
+ * light's acos (binary64: a square root, two divisions, a ten-term series) wherever the cosine of the angle is clear of the
+ * cone's edge by a margin: cos_in / cos_out = cos(spread) +- 1e-4, rounded outwards, computed once per light by rt_scene_create.
+ *   x > cos_in  : the angle is below the spread by ~1e-4, three orders of magnitude more than acosf's last bit: `angle > spread` is false;
+ *   x < cos_out : likewise true: None;
+ *   otherwise (and for NaN, which fails both compares): the reference's own expression.
+ * An x above 1 by rounding makes acosf NaN and `NaN > spread` false — not None — which is also what x > cos_in says.
+ * The colour is not evaluated (the consumer of the SHADE item does that, once). */
+struct LightAux {
+    float cos_in, cos_out;
+};
+template <class Light, class Aux>
+RT_HD bool light_asks(const Light &l, const Aux &aux, V3 position, V3 adj_n, V3 *direction_out) {
+    V3 direction;
+    if (l.kind == RT_LIGHT_DIRECTIONAL) {
+        direction = v3(l.direction[0], l.direction[1], l.direction[2]);
+    } else {
+        const V3 origin = v3(l.origin[0], l.origin[1], l.origin[2]);
+        const V3 offset = position - origin;
+        if (l.kind == RT_LIGHT_SPOT) {
+            const V3 axis = v3(l.direction[0], l.direction[1], l.direction[2]);
+            const float x = dot(axis, offset) / (magnitude(axis) * magnitude(offset)); /* cgmath InnerSpace::angle's argument */
+            if (!(x > aux.cos_in)) {
+                if (x < aux.cos_out) return false;
+                const float angle = rtdm::f_abs(rtdm::acosf(x));
+                if (angle > l.angle) return false;
+            }
+            direction = normalize(position - origin);
+        } else {
+            direction = normalize(offset);
+        }
+    }
+    *direction_out = direction;
+    const float cosine = -dot(direction, adj_n);
+    return !(cosine <= 0.0f);
+}
+
 /* closure at main.rs:329 + normalize at main.rs:333 */
 RT_HD V3 reflect_dir(V3 n, V3 l) { return normalize(l - 2.0f * dot(l, n) * n); }
 
