@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "rt_cast.h"
 #include "rt_pwf_common.h"
@@ -322,61 +323,96 @@ __global__ __launch_bounds__(256) void rng_scan_kernel(const uint32_t *states, u
     if (want) list[1u + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = p;
 }
 
-/* One wave per workgroup, RNG_LDS_SLOTS records at a time: all 64 lanes copy the mem[] of the 8 records into LDS (8 lanes
- * x 128 B each), lanes 0-7 run the steps — one record each, side by side — and all lanes copy the new mem[] out into the
- * other bank.  The steps are latency (two dependent LDS reads each); the chip-wide rate comes from the number of
- * records in flight, which LDS bounds at 160 per CU. */
+/* Every lane generates the next block of ONE record, its mem[] in a column of LDS of its own: word i of the lane's record
+ * at stage[i * SLOTS + lane], SLOTS a multiple of 32, so a lane stays in its bank whatever i it asks for — the two
+ * data-dependent reads of a step never conflict.  Nothing is shared between lanes: no barriers.  mem[i] and mem[i + 128] of
+ * the next four steps are read ahead of the chain (step j only ever writes mem[j], so they cannot be stale), which leaves ONE
+ * LDS latency per step on it (b needs mem[(y >> 10) & 255], the next y needs b), and the four results of a group leave as
+ * one 16-byte store.  Two one-wave workgroups of 64 records (64 KB) per CU.  Measured alone over 2^20 records
+ * (tools/diag_prepare.py, profiles/r03_lookahead_kernel.txt): 1.37 ms against 2.04 ms for round 2's form (8 records per wave
+ * staged by all its lanes, the steps on 8 of the 64, twenty waves per CU: the LDS pipe served 64-lane instructions for 8
+ * lanes' worth of work) — 0.78 ms of steps (~230 clocks each) and 0.92 ms of copies (2.2 TB/s in 16-byte pieces), partly
+ * overlapped.  What the pass gains is more than that: the look-ahead runs beside the shade kernel, and two waves per CU
+ * take far less from it than twenty did (shade kernel 5.97 -> 4.50 ms per batch, the pass 1 073 -> 1 155 Msamples/s).  One
+ * workgroup of 160 lanes with all 160 KB of a CU is as fast alone (1.39 ms) but cannot share a CU with the shade kernel's
+ * workgroups: 1 118 Msamples/s. */
+struct __attribute__((packed, aligned(4))) RngU4 { uint32_t x, y, z, w; }; /* 16 bytes at a word boundary: results[] starts at word 259 */
+
+template <uint32_t SLOTS>
 __global__ __launch_bounds__(64) void rng_prepare_kernel(uint32_t *states, const uint32_t *list) {
-    __shared__ uint32_t stage[RNG_LDS_SLOTS * 256u];
+    extern __shared__ uint32_t rng_prep_stage[]; /* SLOTS x 256 words */
     const uint32_t lane = threadIdx.x;
     const uint32_t count = list[0];
-    const uint32_t k = lane >> 3, part = lane & 7u; /* copy role: record k, words [32 part, 32 part + 32) */
-    for (uint32_t first = blockIdx.x * RNG_LDS_SLOTS; first < count; first += gridDim.x * RNG_LDS_SLOTS) {
-        uint32_t *rec = nullptr, *src = nullptr, *dst = nullptr;
-        if (first + k < count) {
-            rec = states + (size_t)list[1u + first + k] * RNG_WORDS;
-            const uint32_t cur = rec[RNG_FLAGS] & 1u;
-            src = rec + cur * RNG_BANK_WORDS;
-            dst = rec + (cur ^ 1u) * RNG_BANK_WORDS;
-            for (uint32_t i = part * 32u; i < part * 32u + 32u; i += 4u) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(src + RNG_MEM + i);
-                stage[(i + 0u) * RNG_LDS_SLOTS + k] = v.x;
-                stage[(i + 1u) * RNG_LDS_SLOTS + k] = v.y;
-                stage[(i + 2u) * RNG_LDS_SLOTS + k] = v.z;
-                stage[(i + 3u) * RNG_LDS_SLOTS + k] = v.w;
+    uint32_t *m = rng_prep_stage + lane;
+    for (uint32_t first = blockIdx.x * SLOTS; first < count; first += gridDim.x * SLOTS) {
+        if (lane >= SLOTS || first + lane >= count) continue;
+        uint32_t *rec = states + (size_t)list[1u + first + lane] * RNG_WORDS;
+        const uint32_t cur = rec[RNG_FLAGS] & 1u;
+        const uint32_t *src = rec + cur * RNG_BANK_WORDS;
+        uint32_t *dst = rec + (cur ^ 1u) * RNG_BANK_WORDS;
+        for (uint32_t i = 0; i < 256u; i += 32u) { /* eight loads in flight */
+            uint4 v[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) v[j] = *reinterpret_cast<const uint4 *>(src + RNG_MEM + i + 4u * j);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                m[(i + 4u * j + 0u) * SLOTS] = v[j].x;
+                m[(i + 4u * j + 1u) * SLOTS] = v[j].y;
+                m[(i + 4u * j + 2u) * SLOTS] = v[j].z;
+                m[(i + 4u * j + 3u) * SLOTS] = v[j].w;
             }
         }
-        __syncthreads();
-        if (lane < RNG_LDS_SLOTS && first + lane < count) {
-            uint32_t *r = states + (size_t)list[1u + first + lane] * RNG_WORDS;
-            const uint32_t cur = r[RNG_FLAGS] & 1u;
-            isaac_steps_lds(stage + lane, r + cur * RNG_BANK_WORDS, r + (cur ^ 1u) * RNG_BANK_WORDS);
-            r[RNG_FLAGS] = cur | 2u;
+        const uint32_t cc = src[RNG_C] + 1u;
+        uint32_t a = src[RNG_A], b = src[RNG_B] + cc;
+        for (uint32_t i = 0; i < 256u; i += 4u) {
+            const uint32_t x0 = m[(i + 0u) * SLOTS], x1 = m[(i + 1u) * SLOTS], x2 = m[(i + 2u) * SLOTS], x3 = m[(i + 3u) * SLOTS];
+            const uint32_t h0 = m[((i + 128u) & 255u) * SLOTS], h1 = m[((i + 129u) & 255u) * SLOTS], h2 = m[((i + 130u) & 255u) * SLOTS],
+                           h3 = m[((i + 131u) & 255u) * SLOTS];
+            RngU4 r;
+#define RT_ISAAC_WIDE_STEP(K, X, H, MIX, OUT)                         \
+            {                                                         \
+                a = (a ^ (MIX)) + (H);                                \
+                const uint32_t y = a + b + m[(((X) >> 2) & 255u) * SLOTS]; \
+                m[(i + (K)) * SLOTS] = y;                             \
+                b = (X) + m[((y >> 10) & 255u) * SLOTS];              \
+                OUT = b;                                              \
+            }
+            RT_ISAAC_WIDE_STEP(0u, x0, h0, a << 13, r.w)
+            RT_ISAAC_WIDE_STEP(1u, x1, h1, a >> 6, r.z)
+            RT_ISAAC_WIDE_STEP(2u, x2, h2, a << 2, r.y)
+            RT_ISAAC_WIDE_STEP(3u, x3, h3, a >> 16, r.x)
+#undef RT_ISAAC_WIDE_STEP
+            *reinterpret_cast<RngU4 *>(dst + RNG_RESULTS + 252u - i) = r; /* results[255 - i] = step i's word: read forwards */
         }
-        __syncthreads();
-        if (rec != nullptr) {
-            for (uint32_t i = part * 32u; i < part * 32u + 32u; i += 4u) {
+        for (uint32_t i = 0; i < 256u; i += 32u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
                 uint4 v;
-                v.x = stage[(i + 0u) * RNG_LDS_SLOTS + k];
-                v.y = stage[(i + 1u) * RNG_LDS_SLOTS + k];
-                v.z = stage[(i + 2u) * RNG_LDS_SLOTS + k];
-                v.w = stage[(i + 3u) * RNG_LDS_SLOTS + k];
-                *reinterpret_cast<uint4 *>(dst + RNG_MEM + i) = v;
+                v.x = m[(i + 4u * j + 0u) * SLOTS];
+                v.y = m[(i + 4u * j + 1u) * SLOTS];
+                v.z = m[(i + 4u * j + 2u) * SLOTS];
+                v.w = m[(i + 4u * j + 3u) * SLOTS];
+                *reinterpret_cast<uint4 *>(dst + RNG_MEM + i + 4u * j) = v;
             }
         }
-        __syncthreads();
+        dst[RNG_A] = a;
+        dst[RNG_B] = b;
+        dst[RNG_C] = cc;
+        rec[RNG_FLAGS] = cur | 2u;
     }
 }
+
+#ifndef RNG_PREP_SLOTS
+#define RNG_PREP_SLOTS 64u /* records (and KB of LDS) of a one-wave workgroup; a multiple of 32, at most 64 */
+#endif
 
 hipError_t launch_rng_prepare(uint32_t *states, uint32_t n_pixels, uint32_t *list, uint32_t compute_units, hipStream_t stream) {
     if (n_pixels == 0u) return hipSuccess;
     hipError_t e = hipMemsetAsync(list, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rng_scan_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, states, n_pixels, list);
-    uint32_t groups = (n_pixels + RNG_LDS_SLOTS - 1u) / RNG_LDS_SLOTS;
-    const uint32_t resident = compute_units * 20u; /* 8 KB of LDS each */
-    if (groups > resident) groups = resident;
-    hipLaunchKernelGGL(rng_prepare_kernel, dim3(groups), dim3(64), 0, stream, states, list);
+    const uint32_t groups = std::min((n_pixels + RNG_PREP_SLOTS - 1u) / RNG_PREP_SLOTS, compute_units * (160u / RNG_PREP_SLOTS));
+    hipLaunchKernelGGL((rng_prepare_kernel<RNG_PREP_SLOTS>), dim3(groups), dim3(64), RNG_PREP_SLOTS * 1024u, stream, states, list);
     return hipGetLastError();
 }
 
@@ -1281,4 +1317,46 @@ RT_DIAG_NEED_READER(rt_diag_read_need_dist)
 #endif
 #ifdef RT_DIAG_PAIR_TIME
 RT_DIAG_PAIR_TIME_READER(rt_diag_read_pair_time)
+#endif
+#ifdef RT_DIAG_PREPARE
+/* diagnostic build (tools/diag_prepare.py): the look-ahead pass alone over n freshly seeded records, `reps` times (the
+ * prepared flags cleared in between); ms_out[0] = average ms of scan + prepare, ms_out[1] = of the scan alone */
+namespace rt {
+__global__ void rng_diag_unprepare_kernel(uint32_t *states, uint32_t n) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) states[(size_t)p * RNG_WORDS + RNG_FLAGS] &= 1u;
+}
+}
+extern "C" int rt_diag_prepare_time(uint32_t n_records, uint32_t reps, uint32_t compute_units, float *ms_out) {
+    uint32_t *states = nullptr, *list = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&states), (size_t)n_records * rt::RNG_WORDS * sizeof(uint32_t)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void **>(&list), ((size_t)n_records + 1u) * sizeof(uint32_t)) != hipSuccess) return -1;
+    rt::KernelFrame fr = {};
+    fr.cols = n_records; fr.rows = 1u; fr.y_step = 1u;
+    if (rt::launch_rng_seed(states, fr, nullptr) != hipSuccess) return -2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float total = 0.0f, scan = 0.0f;
+    for (uint32_t r = 0; r < reps + 1u; ++r) { /* the first is a warm-up */
+        hipLaunchKernelGGL(rt::rng_diag_unprepare_kernel, dim3((n_records + 255u) / 256u), dim3(256), 0, nullptr, states, n_records);
+        hipEventRecord(e0, nullptr);
+        if (rt::launch_rng_prepare(states, n_records, list, compute_units, nullptr) != hipSuccess) return -3;
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0u) total += ms;
+        hipEventRecord(e0, nullptr);
+        if (rt::launch_rng_prepare(states, n_records, list, compute_units, nullptr) != hipSuccess) return -3; /* nothing left to prepare */
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0u) scan += ms;
+    }
+    ms_out[0] = total / (float)reps;
+    ms_out[1] = scan / (float)reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipFree(states); (void)hipFree(list);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
 #endif
