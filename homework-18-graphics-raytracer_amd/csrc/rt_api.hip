@@ -997,8 +997,8 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
 
 int rt_rng_destroy(rt_rng *rng) {
     if (!rng) return RT_OK;
+    if (rng->aux) (void)hipStreamSynchronize(rng->aux); /* a look-ahead pass may still be writing the records */
     hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
-    if (rng->aux) (void)hipStreamSynchronize(rng->aux);
     if (rng->d_list) (void)hipFree(rng->d_list);
     if (rng->ev_chain) (void)hipEventDestroy(rng->ev_chain);
     if (rng->ev_prepared) (void)hipEventDestroy(rng->ev_prepared);
