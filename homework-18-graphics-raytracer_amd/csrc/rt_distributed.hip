@@ -956,7 +956,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 
 #ifdef RT_DIAG_PAIR_TIME /* per wave: [0] steps, [1..7] rt_cast.h, [8] the kernel, [9] fetching work + shoot_focus, [10] after the cast: the hit and the
                           * level's factor, [11] the level's draws and scatter_hit, [12] get_refract's exit, [13] the rest of the step */
-    unsigned long long diag_dt[14] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long diag_dt[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; /* [14] lanes at work, summed over the steps; [15] steps after the work queue ran dry */
     const unsigned long long diag_t0 = __builtin_readcyclecounter();
     unsigned long long diag_tick = diag_t0;
 #define RT_STEP_TICK(k) { const unsigned long long now_ = __builtin_readcyclecounter(); diag_dt[k] += now_ - diag_tick; diag_tick = now_; }
@@ -1015,6 +1015,8 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         RT_STEP_TICK(9)
         cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds, diag_dt);
         diag_dt[0] += 1ull;
+        diag_dt[14] += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != DP_DONE));
+        if (exhausted) diag_dt[15] += 1ull;
         diag_tick = __builtin_readcyclecounter();
 #else
         cr = cast_pairs(sc, req, phase != DP_DONE, pair_lds); /* all lanes: the idle ones help with the others' pairs */
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 
 #ifdef RT_DIAG_PAIR_TIME
     diag_dt[8] = __builtin_readcyclecounter() - diag_t0;
-    if (lane == 0u) for (int q = 0; q < 14; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
+    if (lane == 0u) for (int q = 0; q < 16; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
 #endif
     if (dp.ray_count != nullptr) {
         uint32_t c = casts;

@@ -47,6 +47,8 @@ assert lib.rt_diag_read_pair_time(buf, 1) == 0
 steps, total = buf[0], buf[8]
 names = {1: "classify nodes", 2: "wave-uniform runs", 3: "leaf set-up", 4: "pair passes", 5: "signed areas", 6: "finish"}
 print(f"chain kernel, {a.epochs} epochs after {a.burn}: {steps} wave-steps, {total / max(steps, 1):.0f} ticks per step, the cast {100.0 * buf[7] / max(total, 1):.1f} % of the wave time")
+if buf[14]:
+    print(f"  lanes at work per step: {buf[14] / max(steps, 1):.1f} of 64; steps after the work queue ran dry: {100.0 * buf[15] / max(steps, 1):.1f} % of all")
 if buf[9] or buf[10]:
     step = {9: "fetching work + shoot_focus", 10: "the hit + the level's factor", 12: "the level's draws + scatter_hit | get_refract's exit", 13: "the rest"}
     print("  outside the cast: " + ", ".join(f"{step[k]} {100.0 * buf[k] / max(total, 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in (9, 10, 12, 13)))
