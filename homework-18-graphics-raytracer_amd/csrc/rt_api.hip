@@ -939,6 +939,10 @@ struct rt_rng {
     hipStream_t aux;
     hipEvent_t ev_chain, ev_prepared;
     bool ahead;
+    /* The shade and unwind kernels of a batch run on a third stream, beside the NEXT batch's chain kernel (two workspaces, used
+     * in turn): they fill what its tail leaves idle.  ev_tail[b]: the unwind that read workspace b has finished. */
+    hipStream_t tail;
+    hipEvent_t ev_tail[2];
     hipStream_t main_stream; /* of the call in progress (for the after-chain hook) */
     uint32_t cols, rows, x0, y0, y_step;
 };
@@ -962,6 +966,8 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     r->compute_units = 256;
     r->aux = nullptr;
     r->ev_chain = r->ev_prepared = nullptr;
+    r->tail = nullptr;
+    r->ev_tail[0] = r->ev_tail[1] = nullptr;
     r->ahead = false;
     r->main_stream = nullptr;
     const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_DEVICE_WORDS * sizeof(uint32_t);
@@ -975,6 +981,9 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_chain, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_prepared, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->tail, hipStreamNonBlocking); /* (at the lowest stream priority: no different, 1 226 against 1 229 Msamples/s) */
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_tail[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_tail[1], hipEventDisableTiming);
     if (e == hipSuccess) {
         rt::KernelFrame kf;
         memset(&kf, 0, sizeof kf);
@@ -988,6 +997,8 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
         if (r->ev_chain) (void)hipEventDestroy(r->ev_chain);
         if (r->ev_prepared) (void)hipEventDestroy(r->ev_prepared);
         if (r->aux) (void)hipStreamDestroy(r->aux);
+        for (int b = 0; b < 2; ++b) if (r->ev_tail[b]) (void)hipEventDestroy(r->ev_tail[b]);
+        if (r->tail) (void)hipStreamDestroy(r->tail);
         delete r;
         return fail_hip("rt_rng_create", e);
     }
@@ -998,11 +1009,14 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
 int rt_rng_destroy(rt_rng *rng) {
     if (!rng) return RT_OK;
     if (rng->aux) (void)hipStreamSynchronize(rng->aux); /* a look-ahead pass may still be writing the records */
+    if (rng->tail) (void)hipStreamSynchronize(rng->tail);
     hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
     if (rng->d_list) (void)hipFree(rng->d_list);
     if (rng->ev_chain) (void)hipEventDestroy(rng->ev_chain);
     if (rng->ev_prepared) (void)hipEventDestroy(rng->ev_prepared);
     if (rng->aux) (void)hipStreamDestroy(rng->aux);
+    for (int b = 0; b < 2; ++b) if (rng->ev_tail[b]) (void)hipEventDestroy(rng->ev_tail[b]);
+    if (rng->tail) (void)hipStreamDestroy(rng->tail);
     delete rng;
     if (e != hipSuccess) return fail_hip("rt_rng_destroy: hipFree", e);
     return RT_OK;
@@ -1071,17 +1085,26 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     rt_scene *mut = const_cast<rt_scene *>(scene);
     if (split && kf.max_depth <= 254) {
         /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
-         * many epochs as fit the workspace cap (RT_AMD_DIST_WS_MB, default 16 GiB; one epoch at least) and never more than 16 — a
-         * visit of a pixel should not need more random words than the block in use plus the one prepared ahead */
-        size_t cap = (size_t)16384 << 20;
+         * many epochs as fit the workspace cap (RT_AMD_DIST_WS_MB, default 32 GiB for the two workspaces of a call of several
+         * batches; one epoch at least) and never more than 16 — a visit of a pixel should not need more random words than the block
+         * in use plus the one prepared ahead */
+        const uint32_t slots = (uint32_t)(kf.max_depth > 0 ? kf.max_depth : 0) + 1u;
+        const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
+        /* Two workspaces, used in turn, when the call has more than one batch: batch k's shade and unwind kernels then run on a
+         * stream of their own beside batch k+1's chain kernel (A/B: RT_AMD_DIST_PIPELINE=0: one workspace, everything in line) */
+        bool pipeline = true;
+        if (const char *v = getenv("RT_AMD_DIST_PIPELINE")) pipeline = !(*v == '0');
+        size_t cap = (size_t)(pipeline ? 32768 : 16384) << 20;
         if (const char *v = getenv("RT_AMD_DIST_WS_MB")) {
             if (*v) cap = (size_t)strtoull(v, nullptr, 10) << 20;
         }
-        const uint32_t slots = (uint32_t)(kf.max_depth > 0 ? kf.max_depth : 0) + 1u;
-        const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
         uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
+        if (pipeline && batch < n_epochs) /* more than one batch: each workspace gets half the cap */
+            batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / 2u / per_epoch));
+        if (batch < n_epochs) batch = (n_epochs + (n_epochs + batch - 1u) / batch - 1u) / ((n_epochs + batch - 1u) / batch); /* as many batches, of equal size */
+        uint32_t n_buf = pipeline && batch < n_epochs ? 2u : 1u;
         size_t o_hdr = 0, o_req = 0, o_shade = 0, o_frame = 0;
-        auto layout = [&](uint32_t epochs) { /* -> bytes */
+        auto layout = [&](uint32_t epochs) { /* -> bytes of ONE workspace */
             auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
             const size_t n_samples = n_pixels * epochs;
             size_t off = 0;
@@ -1092,23 +1115,20 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             return off;
         };
         char *base = nullptr;
+        size_t buf_stride = 0;
         {
             std::lock_guard<std::mutex> lock(mut->ws_mutex);
             Workspace &ws = mut->workspaces[stream];
             if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
-            size_t need = layout(batch);
+            size_t need = layout(batch) * n_buf;
             if (ws.d_split && ws.split_bytes < need) {
                 /* A workspace that holds at least half the batch wanted is used as it is: giving back and obtaining
                  * gigabytes costs far more than the shorter batches do (measured: 0.65 s to replace a 14 GB workspace
                  * by a 16 GB one, against 0.15 s for the 64 epochs the call was made for; profiles/README.md) */
                 uint32_t fit = batch;
-                while (fit > 1u && layout(fit) > ws.split_bytes) fit -= 1u;
-                if (layout(fit) <= ws.split_bytes && fit * 2u >= batch) {
-                    batch = fit;
-                    need = layout(batch);
-                } else {
-                    need = layout(batch);
-                }
+                while (fit > 1u && layout(fit) * n_buf > ws.split_bytes) fit -= 1u;
+                if (layout(fit) * n_buf <= ws.split_bytes && fit * 2u >= batch) batch = fit;
+                need = layout(batch) * n_buf;
             }
             if (ws.split_bytes < need) {
                 if (ws.d_split) {
@@ -1123,34 +1143,57 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                 while (refuse-- > 0 || hipMalloc(&ws.d_split, need) != hipSuccess) {
                     (void)hipGetLastError();
                     ws.d_split = nullptr;
-                    if (batch == 1u) break;
-                    batch = (batch + 1u) / 2u;
-                    need = layout(batch);
+                    if (batch == 1u && n_buf == 1u) break;
+                    if (batch == 1u) n_buf = 1u;
+                    else batch = (batch + 1u) / 2u;
+                    need = layout(batch) * n_buf;
                 }
                 ws.split_bytes = ws.d_split ? need : 0;
             }
             dp.work_queue = ws.d_counters;
             base = static_cast<char *>(ws.d_split);
+            buf_stride = layout(batch); /* sets the offsets for the batch size settled on */
         }
         if (base == nullptr) goto one_kernel;
-        dp.sp_hdr = reinterpret_cast<uint32_t *>(base + o_hdr);
-        dp.sp_req = reinterpret_cast<uint4 *>(base + o_req);
-        dp.sp_shade = reinterpret_cast<float4 *>(base + o_shade);
-        dp.sp_frame = reinterpret_cast<float4 *>(base + o_frame);
+        if (batch >= n_epochs) n_buf = 1u;
         dp.sp_slots = slots;
-        for (uint32_t e0 = 0; e0 < n_epochs; e0 += batch) {
+        uint32_t k = 0;
+        bool tail_used[2] = {false, false};
+        hipError_t e = hipSuccess;
+        for (uint32_t e0 = 0; e0 < n_epochs && e == hipSuccess; e0 += batch, ++k) {
             /* the layout is [slot][sample of THIS batch]: a short last batch just uses a prefix of every array */
+            const uint32_t b = n_buf == 2u ? (k & 1u) : 0u;
+            char *const ws_base = base + (size_t)b * buf_stride;
+            dp.sp_hdr = reinterpret_cast<uint32_t *>(ws_base + o_hdr);
+            dp.sp_req = reinterpret_cast<uint4 *>(ws_base + o_req);
+            dp.sp_shade = reinterpret_cast<float4 *>(ws_base + o_shade);
+            dp.sp_frame = reinterpret_cast<float4 *>(ws_base + o_frame);
             dp.epoch0 = e0;
             dp.n_epochs = std::min(batch, n_epochs - e0);
-            hipError_t e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+            e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
+            if (e == hipSuccess && tail_used[b]) e = hipStreamWaitEvent(stream, rng->ev_tail[b], 0); /* the unwind two batches ago has read this workspace */
             if (e == hipSuccess && lookahead && !rng->ahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
             rng->ahead = false; /* the chain kernel uses blocks up */
             rng->main_stream = stream;
-            if (e == hipSuccess) e = rt::launch_distributed_split(scene->ks, kf, dp, dist_waves, stream, lookahead && overlap ? lookahead_after_chain : nullptr, rng);
+            if (e == hipSuccess) e = rt::launch_dist_chain(scene->ks, kf, dp, dist_waves, stream);
+            /* from here on this batch does not touch the RNG records: the look-ahead for the next one, on its own stream */
+            if (e == hipSuccess && lookahead && overlap) e = lookahead_after_chain(rng);
+            if (n_buf == 2u) {
+                if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], stream); /* first: the chain kernel has written workspace b ... */
+                if (e == hipSuccess) e = hipStreamWaitEvent(rng->tail, rng->ev_tail[b], 0);
+                if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, rng->tail);
+                if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], rng->tail); /* ... then: and the unwind has read it */
+                tail_used[b] = e == hipSuccess;
+            } else if (e == hipSuccess) {
+                e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, stream);
+            }
             /* the next chain kernel — of this call or, on whatever stream is ordered after this one, of the next — needs the prepared blocks */
             if (e == hipSuccess && rng->ahead) e = hipStreamWaitEvent(stream, rng->ev_prepared, 0);
-            if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
         }
+        /* everything the call started is behind the caller's stream again */
+        for (uint32_t b = 0; b < 2u; ++b)
+            if (tail_used[b]) { const hipError_t e2 = hipStreamWaitEvent(stream, rng->ev_tail[b], 0); if (e == hipSuccess) e = e2; }
+        if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
         return RT_OK;
     }
 one_kernel:

@@ -1278,9 +1278,9 @@ size_t distributed_split_bytes_per_sample(int32_t max_depth) {
     return sizeof(uint32_t) + (d + 1u) * (4u * sizeof(uint4) + sizeof(float4)) + d * sizeof(float4);
 }
 
-/* one batch of dp.n_epochs epochs (dp.epoch0 = its first epoch within the call); dp.work_queue zeroed */
-hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream,
-                                    DistAfterChain after_chain, void *after_chain_ctx) {
+/* one batch of dp.n_epochs epochs (dp.epoch0 = its first epoch within the call) in two halves, so that a caller may put them on
+ * different streams: the chain kernel (dp.work_queue zeroed) ... */
+hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
     const uint32_t total = fr.cols * fr.rows;
     if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
     uint32_t waves = (total + 63u) / 64u;
@@ -1291,10 +1291,13 @@ hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr
     }
     if (waves > chain_waves) waves = chain_waves;
     hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
-    if (after_chain != nullptr) {
-        const hipError_t e = after_chain(after_chain_ctx);
-        if (e != hipSuccess) return e;
-    }
+    return hipGetLastError();
+}
+
+/* ... and what only reads its records: the shade kernel and the unwind */
+hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream) {
+    const uint32_t total = fr.cols * fr.rows;
+    if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
     const size_t n_samples = (size_t)total * dp.n_epochs;
     const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
     uint32_t tile = 256u; /* samples per workgroup (18 KB of LDS at depth 8: six workgroups per CU); the two lists must fit 48 KB */

@@ -138,11 +138,11 @@ hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t 
 hipError_t launch_rng_prepare(uint32_t *states, uint32_t n_pixels, uint32_t *list, uint32_t compute_units, hipStream_t stream);
 hipError_t launch_rng_export(const uint32_t *states, uint32_t n_pixels, uint32_t *out, hipStream_t stream);
 hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
-/* after_chain (may be null) is called once the chain kernel is enqueued: from there on the RNG records are not touched
- * by this batch any more, so the caller may start the look-ahead for the next batch next to the shade kernel */
-typedef hipError_t (*DistAfterChain)(void *ctx);
-hipError_t launch_distributed_split(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream,
-                                    DistAfterChain after_chain, void *after_chain_ctx);
+/* the split pass, one batch of dp.n_epochs epochs: the chain kernel (all random draws; dp.work_queue zeroed), and — once it has
+ * finished — the shade and unwind kernels, which only read what it recorded and never touch the RNG records: the caller may start
+ * the look-ahead for the next batch, and the next batch's chain kernel on another workspace, beside them */
+hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
+hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream);
 
 /* post_process / sRGB encode on the device (rt_post.hip) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,

@@ -90,9 +90,11 @@ def test_other_scenes_squares_clusters_and_random_triangles(seed):
         assert np.array_equal(rng.download(), st)
 
 
-@pytest.mark.parametrize("cap_mb,epochs", [("1", 3), ("8", 3), ("8", 5)])
-def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs):
-    """A small workspace cap makes the split pass run the call in batches (1 epoch; 2 + a short last one)."""
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+@pytest.mark.parametrize("cap_mb,epochs", [("1", 3), ("8", 3), ("8", 5), ("16", 7)])
+def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs, pipeline):
+    """A small workspace cap makes the split pass run the call in batches (1 epoch; 2 + a short last one) — over two workspaces
+    used in turn, batch k's shade and unwind kernels beside batch k+1's chain kernel (the default), or in line over one."""
     if not organisation:
         pytest.skip("the fused kernel has no workspace")
     import torch
@@ -101,10 +103,12 @@ def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs):
     frame = rt.Frame.full(96, 72, 5)
     accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
     os.environ["RT_AMD_DIST_WS_MB"] = cap_mb
+    os.environ["RT_AMD_DIST_PIPELINE"] = pipeline
     try:
         rng, s, v, casts = _run_gpu(scene, camera, frame, epochs, accum=accum)
     finally:
         del os.environ["RT_AMD_DIST_WS_MB"]
+        del os.environ["RT_AMD_DIST_PIPELINE"]
     st = _oracle.rng_init(frame)
     ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, epochs)
     assert np.array_equal(v, wv) and np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and casts == wcasts

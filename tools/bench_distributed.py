@@ -28,6 +28,7 @@ ap.add_argument("--calls", type=int, default=3)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--burn", type=int, default=0, help="untimed epochs first: the pixels' random streams drift out of step over the first ~100 epochs, which is the state a long run is in")
+ap.add_argument("--warm", type=int, default=0, help="1: an untimed call of --epochs epochs on a generator of its own first, so that the timed calls find their workspace allocated (bench.py's convention)")
 ap.add_argument("--split", type=int, default=-1, help="1: chain/shade/unwind kernels, 0: the fused kernel, -1: library default")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
@@ -44,6 +45,12 @@ world = rt.reference_world()
 cam = rt.reference_camera()
 scene = rt.Scene(world)
 frame = rtdist.shard_frame(a.width, a.height, a.depth, a.rank, a.world)
+if a.warm:
+    warm = rt.Rng(frame)
+    rt.render_distributed(scene, cam, frame, warm, a.epochs, accum=torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    warm.close()
+    del warm
 t0 = time.perf_counter()
 rng = rt.Rng(frame)
 torch.cuda.synchronize()
