@@ -319,9 +319,12 @@ int rt_set_wavefront_budget(unsigned nodes_per_pixel);
 /* rt_render_distributed has two organisations with bit-identical results (samples, flags, RNG states, cast counts):
  *   1 (default)  three kernels per batch of epochs — the scatter chain with all random draws, every get_shade it
  *                asked for, the unwind + filter + accumulation — over a per-stream workspace (852 B per sample at depth 8,
- *                at most RT_AMD_DIST_WS_MB MiB, default 16384; a batch is as many epochs as fit, 16 at most, and fewer if the device
- *                cannot provide the memory — down to organisation 0 when not even one epoch fits; a workspace that holds at
- *                least half the batch wanted is kept rather than replaced);
+ *                at most RT_AMD_DIST_WS_MB MiB, default 32768 for a call of several batches — which uses two workspaces in turn,
+ *                batch k's get_shade and unwind kernels running beside batch k+1's chain kernel on streams the rt_rng owns, all of
+ *                them behind the caller's stream again when the call returns (RT_AMD_DIST_PIPELINE=0: one workspace, in line) — and
+ *                16384 for one of a single batch; a batch is as many epochs as fit, 16 at most, and fewer if the device cannot
+ *                provide the memory — down to organisation 0 when not even one epoch fits; a workspace that holds at least half
+ *                the batch wanted is kept rather than replaced);
  *   2            round 2's queued chain kernel: measured slower than 1 twice and removed in round 3 — the value now selects 1;
  *   0            one kernel, a lane stays on its pixel through chain, shades and unwind (no workspace).
  * -1 restores the default / the RT_AMD_DIST_SPLIT environment variable. */
