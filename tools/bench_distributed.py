@@ -29,6 +29,7 @@ ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--burn", type=int, default=0, help="untimed epochs first: the pixels' random streams drift out of step over the first ~100 epochs, which is the state a long run is in")
 ap.add_argument("--warm", type=int, default=0, help="1: an untimed call of --epochs epochs on a generator of its own first, so that the timed calls find their workspace allocated (bench.py's convention)")
+ap.add_argument("--fresh", type=int, default=0, help="1: no 1-epoch warm-up on the timed generator: the timed call starts from freshly seeded streams (bench.py's convention; use with --warm 1 --calls 1)")
 ap.add_argument("--split", type=int, default=-1, help="1: chain/shade/unwind kernels, 0: the fused kernel, -1: library default")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
@@ -57,7 +58,8 @@ torch.cuda.synchronize()
 t_seed = time.perf_counter() - t0
 accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-rt.render_distributed(scene, cam, frame, rng, 1, accum=accum)  # warm-up (also advances the stream; fine for timing)
+if not a.fresh:
+    rt.render_distributed(scene, cam, frame, rng, 1, accum=accum)  # warm-up (also advances the stream; fine for timing)
 if a.burn:
     rt.render_distributed(scene, cam, frame, rng, a.burn, accum=accum)
 torch.cuda.synchronize()
