@@ -750,7 +750,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
     int variant = current_variant();
     /* the persistent-wavefront path packs the ray's face mode and the depth left next to a 21-bit primitive id */
     if ((variant & RT_VARIANT_PWF) && (uint64_t)scene->ks.n_triangles + scene->ks.n_spheres >= (1ull << 21)) variant &= ~RT_VARIANT_PWF;
-    if ((variant & RT_VARIANT_PWF) && (scene->ks.n_lights >= (1u << 15) || scene->ks.n_materials >= (1u << 16))) variant &= ~RT_VARIANT_PWF;
+    if ((variant & RT_VARIANT_PWF) && (scene->ks.n_lights >= (1u << 14) || scene->ks.n_materials >= (1u << 16))) variant &= ~RT_VARIANT_PWF; /* a SHADE item's word: 16 + 14 bits */
     const int wf_budget = current_wf_budget();
     rt::PwParams pw;
     memset(&pw, 0, sizeof pw);

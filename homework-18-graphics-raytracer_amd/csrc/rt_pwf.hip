@@ -124,6 +124,10 @@ namespace rt {
 #ifndef PA_LDS_N_PAGES
 #define PA_LDS_N_PAGES 2u /* and for NODE items (3 KB each: the ray, its word and contribution, the node id) */
 #endif
+#ifndef PA_DRAIN_ROOM
+#define PA_DRAIN_ROOM 64u /* measured on the reference frame: SHADE items through the arena 2.68 M -> 2.01 M of 9.2 M, 1.048 -> 1.040 ms (0: off; 127:
+                           * 1.96 M but 1.052 ms; profiles/r03_ab8.txt) */
+#endif
 #define PA_IN_LDS 8u /* type bit: the claimed page is one of an LDS queue */
 #define PA_SPIN_LIMIT (1u << 22)
 
@@ -322,6 +326,17 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 if (count != 0u) type = PA_T_SHADE;
             };
             claim_chain(0u);
+            /* a light's LDS queue with less than PA_DRAIN_ROOM positions left is served before partly filled chain pages: what
+             * does not fit a queue goes through the arena's ring in HBM (80 bytes written and read back per item).  Only while
+             * there are tiles to start: after that the chains are all that the frame waits for */
+            if (PA_DRAIN_ROOM != 0u && type == PA_T_NONE && lds_load(&S.tiles_exhausted) == 0u) {
+                for (uint32_t q = 0; q < PA_LQ; ++q) {
+                    if (lds_load(&S.l[q].alloc) - (lds_load(&S.l_released[q]) << 6) + PA_DRAIN_ROOM > PA_LDS_PAGES * 64u) {
+                        count = pa_claim(&S.l[q], S.ready_l[q], PA_LDS_PAGES - 1u, 0u, &start);
+                        if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS | (q << PA_LQ_SHIFT); break; }
+                    }
+                }
+            }
             if (PA_CHAIN_PARTIAL_MIN != 0u && type == PA_T_NONE) claim_chain(PA_CHAIN_PARTIAL_MIN);
             bool tried_tile = false;
             for (int pass = 0; pass < 2 && type == PA_T_NONE; ++pass) {
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 a = t[PA_F(0u)], b = t[PA_F(1u)], c = t[PA_F(2u)], d = t[PA_F(3u)], e = t[PA_F(4u)];
             }
             if (active) {
-                id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x7fffu; sflags = a.z >> 31;
+                id = a.x; prim = a.y; obj = a.z & 0xffffu; light_i = (a.z >> 16) & 0x3fffu; sflags = a.z >> 30; /* 2: depth 0, 1: nothing below the node */
                 spos = v3(puf(b.x), puf(b.y), puf(b.z)); sum.x = puf(b.w);
                 adj_n = v3(puf(c.x), puf(c.y), puf(c.z)); sum.y = puf(c.w);
                 in_dir = v3(puf(d.x), puf(d.y), puf(d.z)); sum.z = puf(d.w);
@@ -596,9 +611,16 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                                                 : lds_append(&S.n.alloc, want_refl);
             if (!refl_in_lds) overflow = want_refl && k_refl + lds_load(&S.root_alloc) >= pp.node_cap;
             if (want_refl && !overflow) rec_cr = k_refl;
+            /* A node with nothing below it — a miss, a hit at the depth limit, a hit whose material asks for no reflection and no
+             * refraction — is complete once its shade term is: whoever writes that term writes the node's VALUE,
+             * (term + black * rc) + black * fc for the third kind (main.rs:516-518 with both children black), and the node has no
+             * second field and is never folded.  Half of all nodes: 16 bytes less written and read each, and a fold less. */
+            const bool below = active && cr.prim >= 0 && depth > 0u && (want_refl || want_refr);
+            const bool bare = active && cr.prim >= 0 && depth > 0u && !below;
             if (active) {
-                nodes[pa_entry(id, 2u) + PA_F(1u)] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
-                fold_level[id] = (unsigned char)((!from_tile && cr.prim >= 0 && depth > 0u) ? depth : 0u); /* roots are folded by tile */
+                if (below) nodes[pa_entry(id, 2u) + PA_F(1u)] = make_uint4(pfu(fc), 0u, rec_cr, rec_cf);
+                /* the level the node is folded at; roots are folded by tile: 0xff marks one that is complete as it stands */
+                fold_level[id] = (unsigned char)(below ? (from_tile ? 0u : depth) : (from_tile ? 0xffu : 0u));
             }
             /* reflection child (get_reflect, main.rs:328-341) */
             if (want_refl && !overflow) {
@@ -632,9 +654,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             }
             want_shade = next_shadow_ray_in_step(sc, 0u, want_shade, &light_i, nh.pos, adj_n); /* no light needs a cast: get_shade = black */
             /* the record's first field (shade term, rc): written here unless a SHADE item will, with the term filled in */
-            if (active && !want_shade) nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
-            queue_shade(want_shade, id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? 0u : 0x80000000u), light_i, nh.pos, adj_n, req.d, sdiffuse,
-                        v3(0.0f, 0.0f, 0.0f));
+            if (active && !want_shade) {
+                if (bare) { const V3 black = v3(0.0f, 0.0f, 0.0f); acc = (acc + black * rc) + black * fc; }
+                nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
+            }
+            queue_shade(want_shade, id, nh.prim, nh.obj | (light_i << 16) | (depth > 0u ? (bare ? 0x40000000u : 0u) : 0x80000000u), light_i, nh.pos, adj_n, req.d,
+                        sdiffuse, v3(0.0f, 0.0f, 0.0f));
         } else if (type == PA_T_REFR) {
             /* ---- one step of get_refract (main.rs:371-403) ---- */
             bool requeue = false, escape = false;
@@ -740,15 +765,19 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 if (!again) {
                     V3 acc = sum; /* depth 0: the unscaled shade (main.rs:488-490) */
                     float rc = 0.0f;
-                    if (sflags == 0u) {
+                    if ((sflags & 2u) == 0u) {
                         const float shade_contribution = (1.0f - rm.shiness) * (1.0f - rm.transparency);
                         acc = sum * shade_contribution;
                         rc = rm.shiness * (1.0f - rm.transparency); /* main.rs:493, as the node's own step has it */
+                        if ((sflags & 1u) != 0u) { /* nothing below the node: its value (main.rs:516-518 with both children black) */
+                            const V3 black = v3(0.0f, 0.0f, 0.0f);
+                            acc = (acc + black * rc) + black * rm.transparency;
+                        }
                     }
                     nodes[pa_entry(id, 2u)] = make_uint4(pfu(acc.x), pfu(acc.y), pfu(acc.z), pfu(rc));
                 }
             }
-            queue_shade(again, id, prim, obj | (light_i << 16) | (sflags << 31), light_i, spos, adj_n, in_dir, sdiffuse, sum);
+            queue_shade(again, id, prim, obj | (light_i << 16) | (sflags << 30), light_i, spos, adj_n, in_dir, sdiffuse, sum);
         }
 #ifdef PA_STATS
         {
@@ -836,7 +865,8 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                 }
                 if (live[j]) {
                     ra[j] = nodes[pa_entry(id[j], 2u)];
-                    rb[j] = nodes[pa_entry(id[j], 2u) + PA_F(1u)];
+                    rb[j] = make_uint4(0u, 0u, PW_FINAL, PW_NO_CHILD);
+                    if (fold_level[id[j]] != 0xffu) rb[j] = nodes[pa_entry(id[j], 2u) + PA_F(1u)]; /* else complete as it stands: no second field */
                 }
             }
             uint4 cr4[4], cf4[4];
@@ -885,6 +915,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             atomicAdd(pp.global + 10, (uint32_t)(st_t2 - st_t0)); atomicMax(pp.global + 11, (uint32_t)(st_t2 - st_t0)); /* until the last wave left the loop */
             atomicAdd(pp.global + 12, (uint32_t)(st_t3 - st_t2)); atomicMax(pp.global + 13, (uint32_t)(st_t3 - st_t2)); /* fold */
             atomicAdd(pp.global + 14, 1u); atomicAdd(pp.global + 15, S.n.alloc);
+            atomicAdd(pp.global + 25, S.s.alloc); atomicAdd(pp.global + 26, S.f.alloc); atomicAdd(pp.global + 27, S.root_alloc); /* items that went through the arena's rings; nodes at the top */
             atomicMin(pp.global + 16, (uint32_t)(st_t3 - st_t0)); atomicMax(pp.global + 17, (uint32_t)(st_t3 - st_t0));
         }
     }

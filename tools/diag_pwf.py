@@ -14,7 +14,8 @@ from homework_18_graphics_raytracer_amd import _capi
 
 W, H, depth = 1920, 1080, 8
 world_n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-lib = C.CDLL(str(_capi.PKG_DIR / "variants/librt_amd_pastats.so"))
+tag = sys.argv[2] if len(sys.argv) > 2 else "pastats"  # another -DPA_STATS build
+lib = C.CDLL(str(_capi.PKG_DIR / f"variants/librt_amd_{tag}.so"))
 lib.rt_scene_create.argtypes = [C.POINTER(_capi.SceneDesc), C.POINTER(C.c_void_p)]
 lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(_capi.Camera), C.POINTER(_capi.Frame), C.c_void_p, C.c_void_p, C.c_void_p]
 world = rt.reference_world(); cam = rt.reference_camera(); desc = world.desc()
@@ -32,6 +33,7 @@ g = (C.c_uint32 * 32)()
 assert lib.rt_diag_read_pwf(g) == 0
 wgs = g[14]
 print(f"workgroups {wgs}; nodes/WG {g[15] / wgs:.0f}")
+print(f"through the arena (HBM) per frame: {g[15]} NODE items (32 B), {g[25]} SHADE items (80 B), {g[26]} REFR items (48 B); nodes with ids from the top of the arena (roots + LDS-queued): {g[27]}")
 print(f"wave's own loop: mean {g[8] / (8 * wgs) / 100:.1f} us, max {g[9] / 100:.1f} us")
 print(f"until the WG's last wave left the loop: mean {g[10] / wgs / 100:.1f} us, max {g[11] / 100:.1f} us")
 print(f"fold: mean {g[12] / wgs / 100:.1f} us, max {g[13] / 100:.1f} us;  whole WG: min {g[16] / 100:.1f} us, max {g[17] / 100:.1f} us")
