@@ -342,3 +342,11 @@ def test_other_numbers_of_lights(n_lights, variant):
     its queues together — on the wavefront path and the per-pixel kernel."""
     world = _scenes.random_world(40 + n_lights, 30, 3, n_lights=n_lights)
     _check(world, _scenes.camera(7), rt.Frame.full(120, 80, 5), budget=16, variant=variant)
+
+
+@pytest.mark.parametrize("n_lights", [(1 << 14) - 1, 1 << 14])
+def test_as_many_lights_as_a_shade_item_can_name(n_lights):
+    """A SHADE item names its next light in 14 bits (rt_pwf.hip): a scene with 2^14 - 1 lights still renders on the wavefront path,
+    one with 2^14 is handed to the per-pixel kernel — the oracle's frame and cast count either way."""
+    world = _scenes.random_world(5, 12, 1, n_lights=n_lights)
+    _check(world, _scenes.camera(3), rt.Frame.full(16, 8, 1), variant=PWF | 2)
