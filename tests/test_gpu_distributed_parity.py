@@ -385,3 +385,55 @@ def test_other_numbers_of_lights(n_lights):
     assert same.all(), f"{(~same).sum()} channels differ"
     assert np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
     assert np.array_equal(rng.download(), st)
+
+
+def test_two_host_threads_run_pipelined_calls_on_their_own_streams(ctx):
+    """rt_render_distributed from two HOST threads at once, each with its own generator and stream, calls of several batches
+    each (two workspaces per stream used in turn, shade + unwind kernels on the generator's own second stream, the look-ahead on
+    its third): both leave the accumulators, cast counts and generator records of the same calls made one after the other."""
+    import threading
+
+    import torch
+
+    world, camera, scene = ctx
+    frames = [rt.Frame.full(96, 72, 5), rt.Frame.full(80, 60, 6)]
+    calls = (4, 3)
+    os.environ["RT_AMD_DIST_WS_MB"] = "16"  # two epochs per batch at these sizes
+    try:
+        def run(frame, stream=None):
+            rng = rt.Rng(frame)
+            accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            if stream is not None:
+                stream.wait_stream(torch.cuda.current_stream())
+            for n in calls:
+                rt.render_distributed(scene, camera, frame, rng, n, accum=accum, ray_count=cnt, stream=stream)
+            (stream or torch.cuda.current_stream()).synchronize()
+            torch.cuda.synchronize()
+            return accum.cpu().numpy(), int(cnt.item()), rng.download()
+
+        want = [run(f) for f in frames]
+        got, errors = [None, None], []
+        start = threading.Barrier(2)
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(0)
+                stream = torch.cuda.Stream()
+                start.wait()
+                for _ in range(3):
+                    got[k] = run(frames[k], stream)
+            except Exception as exc:  # an exception in a thread must fail the test
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        del os.environ["RT_AMD_DIST_WS_MB"]
+    assert not errors, errors
+    for k in range(2):
+        assert np.array_equal(got[k][0].view(np.uint32), want[k][0].view(np.uint32)) and got[k][1] == want[k][1]
+        assert np.array_equal(got[k][2], want[k][2])
