@@ -278,12 +278,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         for (uint32_t q = 0; q < PA_LQ; ++q) {
             const bool w = want && mine == q;
             if (__builtin_amdgcn_ballot_w64(w) == 0ull) continue;
-            bool fits;
-            const uint32_t k = pa_try_append(&S.l[q], &S.l_released[q], PA_LDS_PAGES * 64u, w, &fits);
-            if (!fits) continue;
-            if (w) pa_store_shade(lds_shade + q * (PA_LDS_PAGES * PA_SHADE_U4 * 64u) + pa_entry(k & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
-            pa_publish(S.ready_l[q], PA_LDS_PAGES - 1u, w, k, &S.gen);
-            want = want && !w;
+            bool fits; /* per lane: a queue takes what it has room for, the rest of the wave's items go on */
+            const uint32_t k = pa_try_append_some(&S.l[q], &S.l_released[q], PA_LDS_PAGES * 64u, w, &fits);
+            if (fits) pa_store_shade(lds_shade + q * (PA_LDS_PAGES * PA_SHADE_U4 * 64u) + pa_entry(k & (PA_LDS_PAGES * 64u - 1u), PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
+            pa_publish(S.ready_l[q], PA_LDS_PAGES - 1u, fits, k, &S.gen);
+            want = want && !fits;
         }
         const uint32_t k = lds_append(&S.s.alloc, want);
         if (want) pa_store_shade(shade_q + pa_entry(k & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);

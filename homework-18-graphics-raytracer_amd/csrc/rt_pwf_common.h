@@ -147,6 +147,30 @@ __device__ __forceinline__ uint32_t pa_try_append(PaQueue *q, const uint32_t *re
     return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+/* all lanes.  The same, taking as many of the wave's items as there is room for: *ok is per lane (the first ones in lane order fit) */
+__device__ __forceinline__ uint32_t pa_try_append_some(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    *ok = false;
+    if (mask == 0ull) return 0u;
+    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+    const int leader = (int)__builtin_ctzll(mask);
+    uint32_t base = 0u, take = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) {
+        for (int tries = 0; tries < 4; ++tries) {
+            const uint32_t a = lds_load(&q->alloc);
+            const uint32_t used = a - (lds_load(released) << 6);
+            const uint32_t t = used >= capacity ? 0u : (capacity - used < n ? capacity - used : n);
+            if (t == 0u) break; /* full */
+            if (atomicCAS(&q->alloc, a, a + t) == a) { base = a; take = t; break; }
+        }
+    }
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    take = (uint32_t)__builtin_amdgcn_readlane((int)take, leader);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    *ok = want && rank < take;
+    return base + rank;
+}
+
 /* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
 template <bool PACKED = false>
 __device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
