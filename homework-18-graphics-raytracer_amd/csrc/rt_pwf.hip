@@ -284,6 +284,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
             pa_publish(S.ready_l[q], PA_LDS_PAGES - 1u, fits, k, &S.gen);
             want = want && !fits;
         }
+#ifdef PA_STATS /* which light's queue had no room */
+        for (uint32_t q = 0; q < 3u; ++q) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(want && (mine < 2u ? mine : 2u) == q);
+            if (m != 0ull && lane == (uint32_t)__builtin_ctzll(m)) atomicAdd(pp.global + 28 + q, (uint32_t)__builtin_popcountll(m));
+        }
+#endif
         const uint32_t k = lds_append(&S.s.alloc, want);
         if (want) pa_store_shade(shade_q + pa_entry(k & ring_mask, PA_SHADE_U4), id, prim, word, spos, adj_n, in_dir, sdiffuse, sum);
         pa_publish<PACKED>(ready_s, ring_page_mask, want, k, &S.gen);
