@@ -30,6 +30,9 @@ if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_need.so ]; then py
 if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_ptime.so ]; then python3 tools/diag_pair_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chain_step_time.txt; fi
 python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 2>&1 | grep -v amdgpu.ids > $O/${TAG}_whitted_vs_r02.txt
 python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 --world 8 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_whitted_vs_r02.txt
-for lib in main nopairs r02; do arg=""; if [ "$lib" != main ]; then arg="--lib $lib"; fi; echo "$lib $(python3 tools/bench_distributed.py --epochs 8 --calls 3 --burn 32 $arg 2>/dev/null | tail -1)"; done > $O/${TAG}_stochastic_vs_r02.txt
+# (round 2's library lacks entry points this tool binds: its number is in profiles/r02_*)
+{ for lib in main nopairs; do arg=""; if [ "$lib" != main ]; then arg="--lib $lib"; fi; echo "$lib $(python3 tools/bench_distributed.py --epochs 8 --calls 3 --burn 32 $arg 2>/dev/null | tail -1)"; done
+  echo "main, 64-epoch calls (pipelined over two workspaces) $(python3 tools/bench_distributed.py --epochs 64 --calls 2 --burn 0 --warm 1 2>/dev/null | tail -1)"
+  echo "main, 64-epoch calls, one workspace (RT_AMD_DIST_PIPELINE=0) $(RT_AMD_DIST_PIPELINE=0 python3 tools/bench_distributed.py --epochs 64 --calls 2 --burn 0 --warm 1 2>/dev/null | tail -1)"; } > $O/${TAG}_stochastic_vs_r02.txt
 if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_pastats.so ]; then python3 tools/diag_pwf.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pwf_phases.txt; fi
 rm -rf $O/${TAG}_stats $O/${TAG}_pmc $O/${TAG}_pmc_dist $O/${TAG}_pmc.*.log $O/${TAG}_pmc_dist.*.log
