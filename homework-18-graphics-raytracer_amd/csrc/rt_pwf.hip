@@ -812,38 +812,91 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
     const uint32_t n_top = S.root_alloc < pp.node_cap - n_nodes ? S.root_alloc : pp.node_cap - n_nodes;
     const uint32_t top_first = pp.node_cap - n_top;
     if (!aborted) {
-        /* levels 1 .. max_depth-1 (children before parents; level max_depth are the roots, folded by tile below).  Thread t
-         * looks after the nodes t, t + 512, t + 1024, ...: neighbouring ids are siblings and cousins of one level, so this
-         * spreads a level's nodes evenly over the threads; their level bytes are fetched sixteen at a time */
-        for (uint32_t left = 1u; left < max_depth; ++left) {
-            for (uint32_t first = threadIdx.x; first < n_nodes + n_top; first += PA_THREADS * 16u) {
-                uint32_t lv[16];
-#pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) {
-                    const uint32_t v = first + k * PA_THREADS;
-                    lv[k] = v < n_nodes + n_top ? (uint32_t)fold_level[v < n_nodes ? v : top_first + (v - n_nodes)] : 0u;
+        /* levels 1 .. max_depth-1 (children before parents; level max_depth are the roots, folded by tile below) */
+        auto fold_node = [&](uint32_t id) {
+            const uint4 a = nodes[pa_entry(id, 2u)], b = nodes[pa_entry(id, 2u) + PA_F(1u)];
+            const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
+            V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
+            if (b.z != PW_NO_CHILD) {
+                const uint4 c = nodes[pa_entry(b.z, 2u)];
+                reflection = v3(puf(c.x), puf(c.y), puf(c.z));
+            }
+            if (b.w != PW_NO_CHILD) {
+                const uint4 c = nodes[pa_entry(b.w, 2u)];
+                refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay; /* main.rs:508 */
+            }
+            const V3 value = (v3(puf(a.x), puf(a.y), puf(a.z)) + reflection * rc) + refraction * fc;
+            float *rec = reinterpret_cast<float *>(nodes + pa_entry(id, 2u));
+            rec[0] = value.x;
+            rec[1] = value.y;
+            rec[2] = value.z;
+        };
+        /* The nodes to fold are listed level by level first — in the LDS that held the SHADE queues, which are empty now — by a
+         * counting sort over the level bytes: two passes over them instead of one per level, and a level's nodes dealt evenly
+         * to the 512 threads, one or two each, all their loads in flight together (the fold is the serial end of a workgroup's
+         * frame: 73 -> ~40 us of a 1.04 ms frame, profiles/r03_ab9.txt).  More nodes than the list holds: the scan per level. */
+        uint32_t *const f_list = reinterpret_cast<uint32_t *>(lds_shade);
+        uint32_t *const f_cursor = reinterpret_cast<uint32_t *>(lds_refr); /* [64]: a level's count, then where its next node goes */
+        uint32_t *const f_start = f_cursor + 64u;                           /* [65] */
+        const uint32_t f_cap = PA_LQ * PA_LDS_PAGES * PA_SHADE_U4 * 64u * 4u;
+        const uint32_t n_all = n_nodes + n_top;
+        static_assert(PA_LDS_F_PAGES * 3u * 64u * 4u >= 129u, "the fold's counters live where the REFR queue was");
+        if (threadIdx.x < 64u) f_cursor[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (uint32_t v0 = 0; v0 < n_all; v0 += PA_THREADS) { /* every thread takes part in every trip: wave-wide ballots below */
+                const uint32_t v = v0 + threadIdx.x;
+                const uint32_t id = v < n_nodes ? v : top_first + (v - n_nodes);
+                uint32_t lv = v < n_all ? (uint32_t)fold_level[id] : 0u;
+                if (lv >= max_depth) lv = 0u; /* 0xff: a complete root */
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(lv != 0u);
+                while (todo != 0ull) { /* one LDS atomic per level present in the wave */
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)__builtin_ctzll(todo));
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(lv == l);
+                    uint32_t base = 0u;
+                    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&f_cursor[l], (uint32_t)__builtin_popcountll(m));
+                    if (pass == 1 && lv == l) {
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+                        const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (at < f_cap) f_list[at] = id;
+                    }
+                    todo &= ~m;
                 }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (threadIdx.x == 0u) { /* counts -> starts = cursors */
+                    uint32_t sum = 0u; /* levels 1 .. max_depth - 1 have nodes (max_depth <= 63: six bits of a queued ray's word) */
+                    for (uint32_t l = 0; l <= max_depth && l < 64u; ++l) { const uint32_t c = f_cursor[l]; f_start[l] = sum; f_cursor[l] = sum; sum += c; }
+                    f_start[64] = sum;
+                }
+                __syncthreads();
+                if (f_start[64] > f_cap) break; /* wave-uniform: LDS */
+            }
+        }
+        const bool listed = f_start[64] <= f_cap;
+#ifdef PA_DIAG_NO_LEVELS /* timing experiment: the wrong image */
+        for (uint32_t left = max_depth; left < max_depth; ++left) {
+#else
+        for (uint32_t left = 1u; left < max_depth; ++left) {
+#endif
+            if (listed) {
+                const uint32_t end = f_start[left + 1u];
+                for (uint32_t i = f_start[left] + threadIdx.x; i < end; i += PA_THREADS) fold_node(f_list[i]);
+            } else {
+                for (uint32_t first = threadIdx.x; first < n_all; first += PA_THREADS * 16u) {
+                    uint32_t lv[16];
 #pragma unroll
-                for (uint32_t k = 0; k < 16u; ++k) {
-                    if (lv[k] != left) continue;
-                    const uint32_t v = first + k * PA_THREADS;
-                    const uint32_t id = v < n_nodes ? v : top_first + (v - n_nodes);
-                    const uint4 a = nodes[pa_entry(id, 2u)], b = nodes[pa_entry(id, 2u) + PA_F(1u)];
-                    const float rc = puf(a.w), fc = puf(b.x), decay = puf(b.y);
-                    V3 reflection = v3(0.0f, 0.0f, 0.0f), refraction = v3(0.0f, 0.0f, 0.0f);
-                    if (b.z != PW_NO_CHILD) {
-                        const uint4 c = nodes[pa_entry(b.z, 2u)];
-                        reflection = v3(puf(c.x), puf(c.y), puf(c.z));
+                    for (uint32_t k = 0; k < 16u; ++k) {
+                        const uint32_t v = first + k * PA_THREADS;
+                        lv[k] = v < n_all ? (uint32_t)fold_level[v < n_nodes ? v : top_first + (v - n_nodes)] : 0u;
                     }
-                    if (b.w != PW_NO_CHILD) {
-                        const uint4 c = nodes[pa_entry(b.w, 2u)];
-                        refraction = v3(puf(c.x), puf(c.y), puf(c.z)) * decay; /* main.rs:508 */
+#pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) {
+                        if (lv[k] != left) continue;
+                        const uint32_t v = first + k * PA_THREADS;
+                        fold_node(v < n_nodes ? v : top_first + (v - n_nodes));
                     }
-                    const V3 value = (v3(puf(a.x), puf(a.y), puf(a.z)) + reflection * rc) + refraction * fc;
-                    float *rec = reinterpret_cast<float *>(nodes + pa_entry(id, 2u));
-                    rec[0] = value.x;
-                    rec[1] = value.y;
-                    rec[2] = value.z;
                 }
             }
             __syncthreads();
@@ -851,7 +904,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         /* the roots, by tile: a wave takes four tiles at a time so that their dependent loads (record, then children)
          * overlap */
         const uint32_t n_started = S.tile_list_count;
+#ifdef PA_DIAG_NO_ROOTS /* timing experiment: no image */
+        for (uint32_t e0 = n_started; e0 < n_started; e0 += PA_WAVES * 4u) {
+#else
         for (uint32_t e0 = threadIdx.x >> 6; e0 < n_started; e0 += PA_WAVES * 4u) {
+#endif
             uint32_t id[4], slot[4];
             uint4 ra[4], rb[4];
             bool live[4];
