@@ -744,6 +744,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         };
                         lit = one_light ? !occluded(uniform_ref(sc.lights + lq)) : !occluded(sc.lights[light_i]);
                     }
+#ifdef PA_STATS /* shadow casts: all, with a hit, occluded */
+                    atomicAdd(pp.global + 18, 1u);
+                    if (cr.prim >= 0) atomicAdd(pp.global + 19, 1u);
+                    if (!lit) atomicAdd(pp.global + 31, 1u);
+#endif
                     if (lit) { /* main.rs:450-461 */
                         Mat m;
                         m.normal = v3(0.0f, 0.0f, 0.0f); /* already folded into adj_n */

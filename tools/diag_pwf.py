@@ -34,6 +34,7 @@ assert lib.rt_diag_read_pwf(g) == 0
 wgs = g[14]
 print(f"workgroups {wgs}; nodes/WG {g[15] / wgs:.0f}")
 print(f"through the arena (HBM) per frame: {g[15]} NODE items (32 B), {g[25]} SHADE items (80 B), {g[26]} REFR items (48 B); nodes with ids from the top of the arena (roots + LDS-queued): {g[27]}")
+print(f"  shadow casts {g[18]}: {g[19]} with a hit ({100.0 * g[19] / max(g[18], 1):.1f} %), {g[31]} occluded ({100.0 * g[31] / max(g[18], 1):.1f} %)")
 print(f"  SHADE items that found no room in the LDS queue of light 0 / 1 / 2+: {g[28]} / {g[29]} / {g[30]}")
 print(f"wave's own loop: mean {g[8] / (8 * wgs) / 100:.1f} us, max {g[9] / 100:.1f} us")
 print(f"until the WG's last wave left the loop: mean {g[10] / wgs / 100:.1f} us, max {g[11] / 100:.1f} us")
