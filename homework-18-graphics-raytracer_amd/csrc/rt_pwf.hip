@@ -311,22 +311,48 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         uint32_t type = PA_T_NONE, start = 0u, count = 0u;
         if (lane == 0u) {
             const uint32_t gen = lds_load(&S.gen); /* before looking: a publish during the look must not be slept through */
+            /* which queues hold unclaimed positions at all — their counters read together, one LDS round trip for all eight:
+             * towards the end of a frame most of them are empty most of the time, and looking at them one after the other (two
+             * dependent reads each) was a microsecond of every step of the chains the frame then waits for.  A queue that gets
+             * its first item after this look is noticed through `gen` (read above), as before. */
+            auto look = [&]() -> uint32_t {
+                const uint32_t a0 = lds_load(&S.ln.alloc), a1 = lds_load(&S.n.alloc), a2 = lds_load(&S.lf.alloc), a3 = lds_load(&S.f.alloc);
+                const uint32_t t0 = lds_load(&S.ln.taken), t1 = lds_load(&S.n.taken), t2 = lds_load(&S.lf.taken), t3 = lds_load(&S.f.taken);
+                uint32_t al[PA_LQ], tl[PA_LQ];
+                for (uint32_t q = 0; q < PA_LQ; ++q) { al[q] = lds_load(&S.l[q].alloc); tl[q] = lds_load(&S.l[q].taken); }
+                const uint32_t as = lds_load(&S.s.alloc), ts = lds_load(&S.s.taken);
+                uint32_t m = (a0 > t0 * 64u ? 1u : 0u) | (a1 > t1 * 64u ? 2u : 0u) | (a2 > t2 * 64u ? 4u : 0u) | (a3 > t3 * 64u ? 8u : 0u);
+                for (uint32_t q = 0; q < PA_LQ; ++q) m |= al[q] > tl[q] * 64u ? 16u << q : 0u;
+                m |= as > ts * 64u ? 16u << PA_LQ : 0u;
+                return m;
+            };
+            uint32_t have = look();
             /* the dependent chains: NODE, then REFR pages (those in LDS first), full ones, then whatever there is */
             auto claim_chain = [&](uint32_t min_partial) {
-                count = pa_claim(&S.ln, S.ready_ln, PA_LDS_N_PAGES - 1u, min_partial, &start);
-                if (count != 0u) { type = PA_T_NODE | PA_IN_LDS; return; }
-                count = pa_claim<PACKED>(&S.n, ready_n, 0xffffffffu, min_partial, &start);
-                if (count != 0u) { type = PA_T_NODE; return; }
-                count = pa_claim(&S.lf, S.ready_lf, PA_LDS_F_PAGES - 1u, min_partial, &start);
-                if (count != 0u) { type = PA_T_REFR | PA_IN_LDS; return; }
-                count = pa_claim<PACKED>(&S.f, ready_f, ring_page_mask, min_partial, &start);
-                if (count != 0u) type = PA_T_REFR;
+                if ((have & 1u) != 0u) {
+                    count = pa_claim(&S.ln, S.ready_ln, PA_LDS_N_PAGES - 1u, min_partial, &start);
+                    if (count != 0u) { type = PA_T_NODE | PA_IN_LDS; return; }
+                }
+                if ((have & 2u) != 0u) {
+                    count = pa_claim<PACKED>(&S.n, ready_n, 0xffffffffu, min_partial, &start);
+                    if (count != 0u) { type = PA_T_NODE; return; }
+                }
+                if ((have & 4u) != 0u) {
+                    count = pa_claim(&S.lf, S.ready_lf, PA_LDS_F_PAGES - 1u, min_partial, &start);
+                    if (count != 0u) { type = PA_T_REFR | PA_IN_LDS; return; }
+                }
+                if ((have & 8u) != 0u) {
+                    count = pa_claim<PACKED>(&S.f, ready_f, ring_page_mask, min_partial, &start);
+                    if (count != 0u) type = PA_T_REFR;
+                }
             };
             auto claim_shade = [&](uint32_t min_partial) {
                 for (uint32_t q = 0; q < PA_LQ; ++q) {
+                    if ((have & (16u << q)) == 0u) continue;
                     count = pa_claim(&S.l[q], S.ready_l[q], PA_LDS_PAGES - 1u, min_partial, &start);
                     if (count != 0u) { type = PA_T_SHADE | PA_IN_LDS | (q << PA_LQ_SHIFT); return; }
                 }
+                if ((have & (16u << PA_LQ)) == 0u) return;
                 count = pa_claim<PACKED>(&S.s, ready_s, ring_page_mask, min_partial, &start);
                 if (count != 0u) type = PA_T_SHADE;
             };
@@ -375,6 +401,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
              * and may add to it; anything once this wave is the last one awake (then nobody will). */
             for (int last = 0; last < 2 && type == PA_T_NONE; ++last) {
                 const uint32_t min_partial = last ? 1u : PA_MIN_PARTIAL;
+                have = look(); /* afresh: the second time round this wave has counted itself the last one awake */
                 claim_chain(min_partial);
                 if (type != PA_T_NONE) break;
                 claim_shade(min_partial);
