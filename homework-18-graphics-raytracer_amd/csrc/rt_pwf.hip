@@ -147,6 +147,7 @@ struct PaShared {
     uint32_t root_alloc;      /* root nodes, handed out from the top of the arena downwards */
     uint32_t tiles_exhausted; /* the frame-wide counter ran out, or this arena has no room for another tile */
     uint32_t tile_list_count;
+    uint32_t static_next;     /* tiles of this workgroup's own share taken so far */
     uint32_t idle;            /* waves asleep: they found nothing and wait for `gen` to move */
     uint32_t gen;             /* bumped whenever items are published */
     uint32_t done;            /* all waves idle at once: the queues are final */
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         S.root_alloc = 0u;
         S.tiles_exhausted = 0u;
         S.tile_list_count = 0u;
+        S.static_next = 0u;
         S.idle = 0u;
         S.gen = 0u;
         S.done = 0u;
@@ -382,7 +384,23 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         if (room < 64u * pp.tile_reserve || lds_load(&S.tile_list_count) >= tile_cap) {
                             S.tiles_exhausted = 1u; /* this arena is nearly full: the other workgroups take the rest */
                         } else {
-                            const uint32_t k = atomicAdd(pp.global + PW_G_TILE, 1u);
+                            /* Half of a workgroup's even share of the tiles are its own — workgroup w takes tiles w, w + G, w + 2 G, ...
+                             * off a counter in LDS — and the rest come from the frame-wide counter, which evens out what the tiles turn out
+                             * to cost; a share of eight tiles or less is the workgroup's own entirely.  One counter word serves ~88 fetches
+                             * per microsecond, and whoever comes first takes: with every tile from it, a 1/8 share's 4 050 tiles went to
+                             * the eight waves each of the 500 workgroups launched first and a third of the chip got none; and in a full
+                             * frame the counter sat on the path of every tile started (profiles/r03_ab11.txt: 1.003 -> 0.939 ms per frame,
+                             * a 1/8 share 0.419 -> 0.336 ms). */
+                            const uint32_t share = n_tiles / gridDim.x;
+#ifdef PA_STATIC_EIGHTHS /* A/B: a fixed fraction */
+                            const uint32_t own = (uint32_t)(((unsigned long long)share * PA_STATIC_EIGHTHS) >> 3);
+#else
+                            const uint32_t own = share / 2u > (share < 8u ? share : 8u) ? share / 2u : (share < 8u ? share : 8u);
+#endif
+                            uint32_t k;
+                            const uint32_t mine = own != 0u && lds_load(&S.static_next) < own ? atomicAdd(&S.static_next, 1u) : own;
+                            if (mine < own) k = blockIdx.x + gridDim.x * mine;
+                            else k = gridDim.x * own + atomicAdd(pp.global + PW_G_TILE, 1u);
                             if (k >= n_tiles) {
                                 S.tiles_exhausted = 1u;
                             } else {
