@@ -299,6 +299,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
 #ifdef PA_STATS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t st_hist[5] = {0u, 0u, 0u, 0u, 0u}; /* chunks by item count: <= 8, <= 16, <= 32, < 64, 64 */
+    uint32_t st_shadow[3] = {0u, 0u, 0u};
     unsigned long long ph[26];
     for (int k = 0; k < 26; ++k) ph[k] = 0ull;
 #endif
@@ -789,10 +790,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
                         };
                         lit = one_light ? !occluded(uniform_ref(sc.lights + lq)) : !occluded(sc.lights[light_i]);
                     }
-#ifdef PA_STATS /* shadow casts: all, with a hit, occluded */
-                    atomicAdd(pp.global + 18, 1u);
-                    if (cr.prim >= 0) atomicAdd(pp.global + 19, 1u);
-                    if (!lit) atomicAdd(pp.global + 31, 1u);
+#ifdef PA_STATS
+                    st_shadow[0] += 1u; /* shadow casts: all, with a hit, occluded (per lane; added up when the wave leaves) */
+                    if (cr.prim >= 0) st_shadow[1] += 1u;
+                    if (!lit) st_shadow[2] += 1u;
 #endif
                     if (lit) { /* main.rs:450-461 */
                         Mat m;
@@ -1019,6 +1020,11 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         const unsigned long long st_t3 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0u) { atomicAdd(pp.global + 8, (uint32_t)(st_t1 - st_t0)); atomicMax(pp.global + 9, (uint32_t)(st_t1 - st_t0)); } /* per wave: own loop */
         if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(pp.global + 20 + k, st_hist[k]);
+        for (int k = 0; k < 3; ++k) {
+            uint32_t v = st_shadow[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0u && v != 0u) atomicAdd(pp.global + (k == 0 ? 18 : (k == 1 ? 19 : 31)), v);
+        }
         if (lane == 0u) {
             ph[25] = st_t3 - st_t2;
             for (int k = 0; k < 26; ++k) atomicAdd(&pa_phase_stats[k], ph[k]);
