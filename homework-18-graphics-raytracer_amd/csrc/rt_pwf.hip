@@ -1038,8 +1038,12 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         }
     }
 #endif
+    /* the workgroup's casts: summed in LDS (in `gen`, which nobody reads any more), one global add per workgroup — by the thread
+     * whose fence and count of workgroups done follow it, so the workgroup that closes the frame reads a complete sum */
+    if (threadIdx.x == 0u) S.gen = 0u;
+    __syncthreads();
     for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
-    if (lane == 0u && casts != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), (unsigned long long)casts);
+    if (lane == 0u && casts != 0u) atomicAdd(&S.gen, casts);
 
     /* ---- the last workgroup to leave closes the frame (no launch of its own for that): every tile rendered and no arena
      * overflow -> publish the cast count; else raise the flag the trailing per-pixel launch looks at.  And it zeroes the
@@ -1047,6 +1051,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
      * per-pixel launch reads the flag from it). ---- */
     __syncthreads();
     if (threadIdx.x == 0u) {
+        if (S.gen != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(pp.global + PW_G_CASTS), (unsigned long long)S.gen);
         __threadfence();
         if (atomicAdd(pp.global + PW_G_GROUPS_DONE, 1u) + 1u == gridDim.x) {
             __threadfence();
