@@ -20,7 +20,8 @@
  * (pa_release_page: pages are released in the order they were claimed).  All 64 lanes of a chunk are
  * in the same phase, so the code between casts runs once; an item is a few dozen bytes, so nothing but the cast's own
  * temporaries is live across the intersection loop (80 VGPRs, six waves per SIMD).  When a workgroup's queues are dry
- * it folds its records bottom-up, value = (shade*sc + reflection*rc) + (refraction*decay)*fc (main.rs:516-518), and
+ * it folds its records bottom-up, value = (shade*sc + reflection*rc) + (refraction*decay)*fc (main.rs:516-518) — the
+ * nodes that have something below them, listed level by level in LDS first; the others were written complete — and
  * writes its pixels.  Subtrees are pure functions of their rays and every helper (rt_shade.h, rt_cast.h) and the
  * association of the fold are the per-pixel kernel's, so the two paths agree bit for bit with each other and with the
  * oracle (tests/test_gpu_wavefront.py).
@@ -28,9 +29,11 @@
  * Scheduling.  There are no barriers in the main loop: every wave loops on its own —
  *
  *   claim a page (64 consecutive queue positions) of NODE, else REFR items, full or not (they are the dependent chains:
- *   a ray_trace activation, its refraction casts, its child, ...); else start a fresh 8x8 tile from the frame-wide
- *   counter while little SHADE work is queued; else a full page of SHADE items (half of all casts of a frame, needed
- *   only at the end: the filler); else a tile; else a partly filled SHADE page; else sleep until somebody publishes
+ *   a ray_trace activation, its refraction casts, its child, ...); else start a fresh 8x8 tile — one of the workgroup's
+ *   own (half of its even share of the frame's tiles; all of it up to eight), then from the frame-wide counter — while
+ *   little SHADE work is queued; else a full page of SHADE items (half of all casts of a frame, needed only at the end:
+ *   the filler); else a tile; else a partly filled SHADE page; else sleep until somebody publishes.  (The counters of all
+ *   eight queues are read together, in one LDS round trip, before any of this.)
  *
  * — so a chain advances as fast as single chunks take and nobody waits for anybody.  (A first version iterated between
  * two barriers, every wave taking up to four chunks per iteration: an item made in one iteration could be picked up in
@@ -50,8 +53,8 @@
  * No wave ever waits for a particular other wave, so there is nothing to deadlock on; an (unreachable) spin limit turns
  * a would-be hang into the overflow fallback.  Root nodes (primary rays) are made in registers and cast at once; their
  * ids come from the top of the arena so that they do not appear in the NODE queue, whose positions are node ids.  No
- * inter-workgroup communication except the tile counter (one atomic per tile; consecutive fetches are spread over the
- * image) and the final cast count.  The two rings never overflow: a node has at most one SHADE and one REFR item alive
+ * inter-workgroup communication except the tile counter (one atomic per tile that is not the workgroup's own; consecutive
+ * fetches are spread over the image) and the final cast count (one add per workgroup).  The two rings never overflow: a node has at most one SHADE and one REFR item alive
  * (plus the successor a wave is writing while the item is still being read), and the rings hold node_cap + 1024 items.
  * Arenas have a fixed capacity: a workgroup stops taking tiles when its arena fills up, and if a frame cannot be
  * finished that way an overflow flag makes the launcher's trailing per-pixel kernel (a no-op otherwise) render it.
