@@ -350,3 +350,12 @@ def test_as_many_lights_as_a_shade_item_can_name(n_lights):
     one with 2^14 is handed to the per-pixel kernel — the oracle's frame and cast count either way."""
     world = _scenes.random_world(5, 12, 1, n_lights=n_lights)
     _check(world, _scenes.camera(3), rt.Frame.full(16, 8, 1), variant=PWF | 2)
+
+
+def test_arenas_that_fill_up_with_own_tiles_left_fall_back(ref):
+    """Half of a workgroup's even share of the tiles are its own (rt_pwf.hip); a workgroup whose arena fills up stops taking tiles, its
+    own ones included, and nobody else will take those: the frame's tile count then falls short, the last workgroup raises the
+    overflow flag and the per-pixel kernel renders the frame.  1280x720 at one node per pixel: 18 tiles per workgroup, arenas a third
+    of what the frame needs — the oracle's frame and cast count all the same."""
+    world, cam, scene = ref
+    _check(world, cam, rt.Frame.full(1280, 720, 8), budget=1, scene=scene)
