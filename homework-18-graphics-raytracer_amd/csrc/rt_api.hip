@@ -943,6 +943,10 @@ struct rt_rng {
      * in turn): they fill what its tail leaves idle.  ev_tail[b]: the unwind that read workspace b has finished. */
     hipStream_t tail;
     hipEvent_t ev_tail[2];
+    /* the chain kernel's pixels grouped by what their samples cost (rt_kernels.h DistParams::pixel_order): per pixel its cost in the
+     * last batch unwound | two orders, one per workspace of a pipelined call | 512 words of scratch */
+    uint32_t *d_pix;
+    bool order_valid[2];
     hipStream_t main_stream; /* of the call in progress (for the after-chain hook) */
     uint32_t cols, rows, x0, y0, y_step;
 };
@@ -968,6 +972,8 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     r->ev_chain = r->ev_prepared = nullptr;
     r->tail = nullptr;
     r->ev_tail[0] = r->ev_tail[1] = nullptr;
+    r->d_pix = nullptr;
+    r->order_valid[0] = r->order_valid[1] = false;
     r->ahead = false;
     r->main_stream = nullptr;
     const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_DEVICE_WORDS * sizeof(uint32_t);
@@ -978,6 +984,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_list), ((size_t)r->cols * r->rows + 1u) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_pix), ((size_t)r->cols * r->rows * 3u + 512u) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_chain, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_prepared, hipEventDisableTiming);
@@ -994,6 +1001,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (e != hipSuccess) {
         if (r->d_states) (void)hipFree(r->d_states);
         if (r->d_list) (void)hipFree(r->d_list);
+        if (r->d_pix) (void)hipFree(r->d_pix);
         if (r->ev_chain) (void)hipEventDestroy(r->ev_chain);
         if (r->ev_prepared) (void)hipEventDestroy(r->ev_prepared);
         if (r->aux) (void)hipStreamDestroy(r->aux);
@@ -1012,6 +1020,7 @@ int rt_rng_destroy(rt_rng *rng) {
     if (rng->tail) (void)hipStreamSynchronize(rng->tail);
     hipError_t e = rng->d_states ? hipFree(rng->d_states) : hipSuccess;
     if (rng->d_list) (void)hipFree(rng->d_list);
+    if (rng->d_pix) (void)hipFree(rng->d_pix);
     if (rng->ev_chain) (void)hipEventDestroy(rng->ev_chain);
     if (rng->ev_prepared) (void)hipEventDestroy(rng->ev_prepared);
     if (rng->aux) (void)hipStreamDestroy(rng->aux);
@@ -1069,6 +1078,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.valid = d_valid;
     dp.ray_count = d_ray_count;
     dp.work_queue = nullptr;
+    dp.pixel_order = nullptr;
+    dp.pixel_cost = nullptr;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
     int split = g_dist_split.load();
@@ -1094,6 +1105,10 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
          * stream of their own beside batch k+1's chain kernel (A/B: RT_AMD_DIST_PIPELINE=0: one workspace, everything in line) */
         bool pipeline = true;
         if (const char *v = getenv("RT_AMD_DIST_PIPELINE")) pipeline = !(*v == '0');
+        /* the chain kernel's pixels grouped by cost when a lane gets two of them at most (rt_kernels.h DistParams::pixel_order);
+         * A/B: RT_AMD_DIST_BY_COST=0 never, =1 always */
+        bool by_cost = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves);
+        if (const char *v = getenv("RT_AMD_DIST_BY_COST")) by_cost = !(*v == '0');
         size_t cap = (size_t)(pipeline ? 32768 : 16384) << 20;
         if (const char *v = getenv("RT_AMD_DIST_WS_MB")) {
             if (*v) cap = (size_t)strtoull(v, nullptr, 10) << 20;
@@ -1175,6 +1190,11 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             if (e == hipSuccess && lookahead && !rng->ahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
             rng->ahead = false; /* the chain kernel uses blocks up */
             rng->main_stream = stream;
+            /* the pixels in the order of what they cost in the batch that used this workspace last (two batches ago in a pipelined
+             * call, the last one else): rt_kernels.h DistParams::pixel_order */
+            uint32_t *const pix_cost = rng->d_pix, *const pix_order = rng->d_pix + (size_t)(1u + b) * n_pixels, *const pix_scratch = rng->d_pix + 3u * n_pixels;
+            dp.pixel_cost = by_cost ? pix_cost : nullptr;
+            dp.pixel_order = by_cost && rng->order_valid[b] ? pix_order : nullptr;
             if (e == hipSuccess) e = rt::launch_dist_chain(scene->ks, kf, dp, dist_waves, stream);
             /* from here on this batch does not touch the RNG records: the look-ahead for the next one, on its own stream */
             if (e == hipSuccess && lookahead && overlap) e = lookahead_after_chain(rng);
@@ -1182,10 +1202,18 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                 if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], stream); /* first: the chain kernel has written workspace b ... */
                 if (e == hipSuccess) e = hipStreamWaitEvent(rng->tail, rng->ev_tail[b], 0);
                 if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, rng->tail);
+                if (e == hipSuccess && by_cost) {
+                    e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, rng->tail);
+                    rng->order_valid[b] = e == hipSuccess;
+                }
                 if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], rng->tail); /* ... then: and the unwind has read it */
                 tail_used[b] = e == hipSuccess;
             } else if (e == hipSuccess) {
                 e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, stream);
+                if (e == hipSuccess && by_cost) {
+                    e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, stream);
+                    rng->order_valid[b] = e == hipSuccess;
+                }
             }
             /* the next chain kernel — of this call or, on whatever stream is ordered after this one, of the next — needs the prepared blocks */
             if (e == hipSuccess && rng->ahead) e = hipStreamWaitEvent(stream, rng->ev_prepared, 0);

@@ -986,13 +986,20 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
             const uint32_t avail = q_end - q_next;
             if (phase == DP_DONE && rank < avail) {
                 const uint32_t slot = q_next + rank;
-                const uint32_t band = slot / band_slots;
-                const uint32_t r = slot - band * band_slots;
-                const uint32_t rows_left = fr.rows - (band << 3);
-                const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
-                const uint32_t col = r / band_rows;
-                const uint32_t row = (band << 3) + (r - col * band_rows);
-                out_index = row * fr.cols + col;
+                uint32_t row, col;
+                if (dp.pixel_order != nullptr) { /* the pixels grouped by cost (rt_kernels.h) */
+                    out_index = dp.pixel_order[slot];
+                    row = out_index / fr.cols;
+                    col = out_index - row * fr.cols;
+                } else { /* the image in 8-row bands, column by column: a chunk is an 8 x 8 tile */
+                    const uint32_t band = slot / band_slots;
+                    const uint32_t r = slot - band * band_slots;
+                    const uint32_t rows_left = fr.rows - (band << 3);
+                    const uint32_t band_rows = rows_left < 8u ? rows_left : 8u;
+                    col = r / band_rows;
+                    row = (band << 3) + (r - col * band_rows);
+                    out_index = row * fr.cols + col;
+                }
                 const uint32_t x = fr.x0 + col, y = fr.y0 + row * fr.y_step;
                 clip_y = (fr.half_height - (float)y) / fr.height_f;
                 clip_x = ((float)x - fr.half_width) / fr.height_f;
@@ -1240,11 +1247,13 @@ __global__ __launch_bounds__(256) void dist_unwind_kernel(const DistParams dp, c
     const size_t n_samples = n_pixels * dp.n_epochs;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pixels; p += (size_t)gridDim.x * blockDim.x) {
         V3 accum = v3(0.0f, 0.0f, 0.0f);
+        uint32_t cost = 0u; /* of the pixel's samples of this batch: a cast per level and the primary one */
         if (dp.accum != nullptr) accum = v3(dp.accum[p * 3u], dp.accum[p * 3u + 1u], dp.accum[p * 3u + 2u]);
         for (uint32_t e = 0; e < dp.n_epochs; ++e) {
             const size_t s = (size_t)e * n_pixels + p;
             const uint32_t hdr = dp.sp_hdr[s];
             const uint32_t frames = hdr & 0xffu;
+            cost += frames + 1u;
             V3 value = v3(0.0f, 0.0f, 0.0f);
             if ((hdr >> 8) & 1u) {
                 const float4 t = dp.sp_shade[(size_t)frames * n_samples + s];
@@ -1276,7 +1285,53 @@ __global__ __launch_bounds__(256) void dist_unwind_kernel(const DistParams dp, c
             dp.accum[p * 3u + 1u] = accum.y;
             dp.accum[p * 3u + 2u] = accum.z;
         }
+        if (dp.pixel_cost != nullptr) dp.pixel_cost[p] = (cost * 8u + dp.n_epochs - 1u) / dp.n_epochs; /* eighths of a cast per sample */
     }
+}
+
+/* ---- the chain kernel's pixels grouped by cost (rt_kernels.h DistParams::pixel_order): a counting sort in three launches ----
+ * scratch[0..255] the histogram, scratch[256..511] the buckets' cursors; dearest first; the order within a bucket is whatever the
+ * atomics make it (it only orders work) */
+#define DIST_ORDER_CHUNK 4096u
+__global__ __launch_bounds__(256) void dist_order_hist_kernel(const uint32_t *cost, uint32_t n, uint32_t *scratch) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * DIST_ORDER_CHUNK;
+    for (uint32_t i = first + threadIdx.x; i < first + DIST_ORDER_CHUNK && i < n; i += 256u) atomicAdd(&h[cost[i] < 255u ? cost[i] : 255u], 1u);
+    __syncthreads();
+    if (h[threadIdx.x] != 0u) atomicAdd(&scratch[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void dist_order_scan_kernel(uint32_t *scratch) {
+    if (threadIdx.x == 0u) {
+        uint32_t sum = 0u;
+        for (int b = 255; b >= 0; --b) { scratch[256 + b] = sum; sum += scratch[b]; }
+    }
+}
+__global__ __launch_bounds__(256) void dist_order_scatter_kernel(const uint32_t *cost, uint32_t n, uint32_t *scratch, uint32_t *order) {
+    __shared__ uint32_t h[256], base[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * DIST_ORDER_CHUNK;
+    for (uint32_t i = first + threadIdx.x; i < first + DIST_ORDER_CHUNK && i < n; i += 256u) atomicAdd(&h[cost[i] < 255u ? cost[i] : 255u], 1u);
+    __syncthreads();
+    base[threadIdx.x] = h[threadIdx.x] != 0u ? atomicAdd(&scratch[256u + threadIdx.x], h[threadIdx.x]) : 0u; /* this workgroup's stretch of the bucket */
+    __syncthreads();
+    for (uint32_t i = first + threadIdx.x; i < first + DIST_ORDER_CHUNK && i < n; i += 256u) {
+        const uint32_t b = cost[i] < 255u ? cost[i] : 255u;
+        order[atomicAdd(&base[b], 1u)] = i;
+    }
+}
+
+hipError_t launch_dist_pixel_order(const uint32_t *cost, uint32_t *order, uint32_t n_pixels, uint32_t *scratch, hipStream_t stream) {
+    if (n_pixels == 0u) return hipSuccess;
+    hipError_t e = hipMemsetAsync(scratch, 0, 256u * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t groups = (n_pixels + DIST_ORDER_CHUNK - 1u) / DIST_ORDER_CHUNK;
+    hipLaunchKernelGGL(dist_order_hist_kernel, dim3(groups), dim3(256), 0, stream, cost, n_pixels, scratch);
+    hipLaunchKernelGGL(dist_order_scan_kernel, dim3(1), dim3(256), 0, stream, scratch);
+    hipLaunchKernelGGL(dist_order_scatter_kernel, dim3(groups), dim3(256), 0, stream, cost, n_pixels, scratch, order);
+    return hipGetLastError();
 }
 
 size_t distributed_split_bytes_per_sample(int32_t max_depth) {
@@ -1286,15 +1341,21 @@ size_t distributed_split_bytes_per_sample(int32_t max_depth) {
 
 /* one batch of dp.n_epochs epochs (dp.epoch0 = its first epoch within the call) in two halves, so that a caller may put them on
  * different streams: the chain kernel (dp.work_queue zeroed) ... */
-hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
-    const uint32_t total = fr.cols * fr.rows;
-    if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
-    uint32_t waves = (total + 63u) / 64u;
+/* the waves the chain kernel's grid has at most: as many as are resident together */
+uint32_t dist_chain_waves(uint32_t resident_waves) {
     uint32_t chain_waves = resident_waves / 3u * (uint32_t)RT_DIST_CHAIN_MIN_WAVES; /* resident_waves is sized for 3 per SIMD */
     if (const char *v = getenv("RT_AMD_DIST_CHAIN_WAVES")) { /* A/B: waves per SIMD of the chain kernel's grid */
         const uint32_t per_simd = (uint32_t)atoi(v);
         if (per_simd >= 1u && per_simd <= (uint32_t)RT_DIST_CHAIN_MIN_WAVES) chain_waves = resident_waves / 3u * per_simd;
     }
+    return chain_waves;
+}
+
+hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream) {
+    const uint32_t total = fr.cols * fr.rows;
+    if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
+    uint32_t waves = (total + 63u) / 64u;
+    const uint32_t chain_waves = dist_chain_waves(resident_waves);
     if (waves > chain_waves) waves = chain_waves;
     hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     return hipGetLastError();

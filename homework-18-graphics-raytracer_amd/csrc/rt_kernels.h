@@ -129,6 +129,15 @@ struct DistParams {
     float4 *sp_shade;              /* [slot][sample]: get_shade results */
     float4 *sp_frame;              /* [level][sample]: factor.xyz, kind */
     uint32_t sp_slots;             /* max_depth + 1 */
+    /* Which pixel a lane of the chain kernel takes next: position q of its queue -> pixel_order[q] (null: the tiled image order).
+     * The order groups the pixels by what their samples cost in an earlier batch (pixel_cost, written by the unwind kernel; null:
+     * not kept), dearest first: a wave keeps stepping until the last of its 64 lanes has finished its pixel, so lanes with pixels
+     * of like cost finish together — what decides the kernel's time when a GPU's share has no more pixels than the chip has lanes.
+     * Used (rt_api.hip) when a lane gets two pixels at most: a 1/8 share of the 1080p frame 0.41 -> 0.38 ms per epoch, 1/4 0.60 ->
+     * 0.565; with more pixels per lane the lanes even out by themselves and neighbouring pixels' rays are worth more: the whole
+     * frame 1.68 -> 1.75 ms (profiles/r03_ab12.txt) */
+    const uint32_t *pixel_order;
+    uint32_t *pixel_cost;
 };
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
@@ -141,8 +150,11 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
 /* the split pass, one batch of dp.n_epochs epochs: the chain kernel (all random draws; dp.work_queue zeroed), and — once it has
  * finished — the shade and unwind kernels, which only read what it recorded and never touch the RNG records: the caller may start
  * the look-ahead for the next batch, and the next batch's chain kernel on another workspace, beside them */
+uint32_t dist_chain_waves(uint32_t resident_waves); /* the chain kernel's grid, at most */
 hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
 hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream);
+/* order[] <- the pixels 0 .. n-1 grouped by cost[] (clipped to 255), dearest first; scratch: 512 words */
+hipError_t launch_dist_pixel_order(const uint32_t *cost, uint32_t *order, uint32_t n_pixels, uint32_t *scratch, hipStream_t stream);
 
 /* post_process / sRGB encode on the device (rt_post.hip) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,
