@@ -1080,6 +1080,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.work_queue = nullptr;
     dp.pixel_order = nullptr;
     dp.pixel_cost = nullptr;
+    dp.own_first_chunk = 0u;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
     int split = g_dist_split.load();
@@ -1109,6 +1110,8 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
          * A/B: RT_AMD_DIST_BY_COST=0 never, =1 always */
         bool by_cost = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves);
         if (const char *v = getenv("RT_AMD_DIST_BY_COST")) by_cost = !(*v == '0');
+        dp.own_first_chunk = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves) ? 1u : 0u; /* rt_kernels.h */
+        if (const char *v = getenv("RT_AMD_DIST_OWN_FIRST")) dp.own_first_chunk = *v == '0' ? 0u : 1u; /* A/B */
         bool prep_first = true; /* A/B: RT_AMD_DIST_PREP_FIRST=0: shade kernel and look-ahead start together */
         if (const char *v = getenv("RT_AMD_DIST_PREP_FIRST")) prep_first = !(*v == '0');
         size_t cap = (size_t)(pipeline ? 32768 : 16384) << 20;

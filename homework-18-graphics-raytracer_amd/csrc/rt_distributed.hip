@@ -886,8 +886,10 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     const uint32_t band_slots = fr.cols << 3;
     const size_t n_pixels = total_slots;
     const size_t n_samples = n_pixels * dp.n_epochs; /* of this batch */
-    uint32_t q_next = 0u, q_end = 0u;
-    bool exhausted = false, first_chunk = true;
+    /* dp.own_first_chunk: a wave's first chunk is its own — chunk w for wave w: the grid never has more waves than there are chunks */
+    uint32_t q_next = dp.own_first_chunk != 0u ? blockIdx.x * 64u : 0u;
+    uint32_t q_end = dp.own_first_chunk != 0u ? (q_next + 64u < total_slots ? q_next + 64u : total_slots) : 0u;
+    bool exhausted = false;
     uint32_t out_index = 0u;
     float clip_x = 0.0f, clip_y = 0.0f;
     const V3 cam_x = v3(fr.cam_x[0], fr.cam_x[1], fr.cam_x[2]);
@@ -969,15 +971,9 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
         while (need != 0ull) {
             if (q_next == q_end) {
                 if (exhausted) break;
-                /* a wave's first chunk is its own (chunk w for wave w: the grid never has more waves than there are chunks); the
-                 * rest come from the counter — at a launch every wave asks at once, and one counter word serves ~88 of them per
-                 * microsecond: 58 us for the 5 120 waves of a chain kernel that, on a 1/8 share of the frame, runs for a millisecond */
-                uint32_t c = blockIdx.x;
-                if (!first_chunk) {
-                    if (lane == 0u) c = atomicAdd(dp.work_queue, 1u);
-                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) + gridDim.x;
-                }
-                first_chunk = false;
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(dp.work_queue, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) + (dp.own_first_chunk != 0u ? gridDim.x : 0u); /* with own first chunks, 0 .. G - 1 are taken */
                 if (c * 64u >= total_slots) { exhausted = true; break; }
                 q_next = c * 64u;
                 q_end = q_next + 64u < total_slots ? q_next + 64u : total_slots;
@@ -987,7 +983,7 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
             if (phase == DP_DONE && rank < avail) {
                 const uint32_t slot = q_next + rank;
                 uint32_t row, col;
-                if (dp.pixel_order != nullptr) { /* the pixels grouped by cost (rt_kernels.h) */
+                if (DUMMY != 0) { /* instantiation 1: the pixels grouped by cost (rt_kernels.h); its own, so that instantiation 0 does not carry it */
                     out_index = dp.pixel_order[slot];
                     row = out_index / fr.cols;
                     col = out_index - row * fr.cols;
@@ -1357,7 +1353,8 @@ hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const
     uint32_t waves = (total + 63u) / 64u;
     const uint32_t chain_waves = dist_chain_waves(resident_waves);
     if (waves > chain_waves) waves = chain_waves;
-    hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    if (dp.pixel_order != nullptr) hipLaunchKernelGGL((dist_chain_kernel<1>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+    else hipLaunchKernelGGL((dist_chain_kernel<0>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     return hipGetLastError();
 }
 

@@ -138,6 +138,12 @@ struct DistParams {
      * frame 1.68 -> 1.75 ms (profiles/r03_ab12.txt) */
     const uint32_t *pixel_order;
     uint32_t *pixel_cost;
+    /* != 0: a wave's first 64-pixel chunk is its own (chunk w for wave w) and only the later ones come from the work counter.  For a
+     * share with few chunks per wave: every wave asks at once at a launch, one counter word serves ~88 of them per microsecond, and
+     * the chain kernel of a 1/8 share runs for a millisecond (0.422 -> 0.410 ms per epoch).  On the whole frame the counter's
+     * staggered answers are worth more than they cost — waves that start together stay in step and ask memory together: 1 165 ->
+     * 1 126 Msamples/s in 8-epoch calls with every wave's first chunk its own (profiles/r03_ab12.txt) */
+    uint32_t own_first_chunk;
 };
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
