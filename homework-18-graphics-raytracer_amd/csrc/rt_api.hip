@@ -985,6 +985,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_list), ((size_t)r->cols * r->rows + 1u) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_pix), ((size_t)r->cols * r->rows * 3u + 512u) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(r->d_pix, 0, ((size_t)r->cols * r->rows * 3u + 512u) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_chain, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_prepared, hipEventDisableTiming);

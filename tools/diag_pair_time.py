@@ -28,11 +28,12 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--epochs", type=int, default=8)
 ap.add_argument("--burn", type=int, default=32)
+ap.add_argument("--world", type=int, default=1, help="rank 0's interleaved row band of this many ranks (a multi-GPU share)")
 a = ap.parse_args()
 lib = _capi.amd_lib()
 lib.rt_diag_read_pair_time.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 world, cam = rt.reference_world(), rt.reference_camera()
-frame = rt.Frame.full(a.width, a.height, a.depth)
+frame = rt.Frame.full(a.width, a.height, a.depth) if a.world == 1 else rt.Frame.rows_of_rank(a.width, a.height, a.depth, 0, a.world)
 scene = rt.Scene(world)
 rng = rt.Rng(frame)
 accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
