@@ -1152,6 +1152,9 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
     __syncthreads();
     uint32_t casts = 0u;
     RT_SHADE_TICK(0)
+#if defined(RT_AB_SHADE_STUB) && RT_AB_SHADE_STUB == 3
+    if (shade_list[0] != 0xffffffffu) return;
+#endif
     for (uint32_t first = (threadIdx.x >> 6) * 64u; first < total; first += blockDim.x) {
         const bool active = first + lane < total;
         V3 pos = v3(0.0f, 0.0f, 0.0f), normal = v3(0.0f, 0.0f, 1.0f), view = v3(0.0f, 0.0f, 1.0f);
@@ -1172,7 +1175,12 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
         const V3 adj_n = adjust_normal(m.normal, normal); /* main.rs:410 */
         V3 sum = v3(0.0f, 0.0f, 0.0f);
         RT_SHADE_TICK(1)
+#if defined(RT_AB_SHADE_STUB) && RT_AB_SHADE_STUB == 2
+        sum = adj_n + m.diffuse;
+        for (uint32_t light_i = 0; light_i < 0u; ++light_i) {
+#else
         for (uint32_t light_i = 0; light_i < sc.n_lights; ++light_i) { /* wave-uniform */
+#endif
             const auto &L = uniform_ref(sc.lights + light_i);
             DirLight dl;
             dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
@@ -1194,7 +1202,9 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
             cr.t = 0.0f;
             cr.bf = 0u;
             cr.a0 = cr.a1 = cr.a2 = 0.0f;
+#if !defined(RT_AB_SHADE_STUB) || RT_AB_SHADE_STUB != 1 /* attribution builds (profiles/r04_shade_attribution.txt): 1 no cast, 2 no light loop, 3 the lists only */
             if (need) cr = cast_asm(sc, req);
+#endif
 #ifdef RT_DIAG_PAIR_TIME
             RT_SHADE_TICK(3)
             sdt[6] += 1ull;

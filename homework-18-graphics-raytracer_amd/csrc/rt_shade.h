@@ -187,7 +187,8 @@ RT_HD bool approximate_into_directional(const Light &l, V3 position, DirLight *o
  *   x > cos_in  : the angle is below the spread by ~1e-4, three orders of magnitude more than acosf's last bit: `angle > spread` is false;
  *   x < cos_out : likewise true: None;
  *   otherwise (and for NaN, which fails both compares): the reference's own expression.
- * An x above 1 by rounding makes acosf NaN and `NaN > spread` false — not None — which is also what x > cos_in says.
+ * An x above 1 by rounding makes acosf NaN and `NaN > spread` false — not None — which is also what x > cos_in says; an x below -1
+ * (a point behind the light, on its axis) does the same at the other end, so the shortcut to None is only taken for x >= -1.
  * The colour is not evaluated (the consumer of the SHADE item does that, once). */
 struct LightAux {
     float cos_in, cos_out;
@@ -204,7 +205,7 @@ RT_HD bool light_asks(const Light &l, const Aux &aux, V3 position, V3 adj_n, V3 
             const V3 axis = v3(l.direction[0], l.direction[1], l.direction[2]);
             const float x = dot(axis, offset) / (magnitude(axis) * magnitude(offset)); /* cgmath InnerSpace::angle's argument */
             if (!(x > aux.cos_in)) {
-                if (x < aux.cos_out) return false;
+                if (x < aux.cos_out && x >= -1.0f) return false; /* below -1 (by rounding, behind the light on its axis) acosf is NaN as well: the light asks */
                 const float angle = rtdm::f_abs(rtdm::acosf(x));
                 if (angle > l.angle) return false;
             }
