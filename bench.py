@@ -46,6 +46,7 @@ def parse_args():
     p.add_argument("--no-pipelined", action="store_true", help="skip the extra measurement with two frames in flight (after the headline's timed region)")
     p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
+    p.add_argument("--no-extras", action="store_true", help="skip the sharded_finish and share_timing objects (after everything else)")
     return p.parse_args()
 
 
@@ -98,6 +99,27 @@ STOCHASTIC_EPOCHS = 64  # BASELINE.json configs[3]: 64 depth-of-field samples pe
 SCATTER_EPOCHS = 5      # BASELINE.json configs[4] / SURVEY §8(d) "Config 5": 10 368 000 = 1920 x 1080 x 5 (pixel, epoch) samples
 
 
+def traffic_record(name, match):
+    """profiles/<name> when it describes THIS workload (`match`: key -> value) and was collected with THESE sources
+    (`sources_sha256`, tools/make_traffic.py) — else (None, why): a kernel change without a fresh counter profile must read as null,
+    not as a stale number."""
+    from homework_18_graphics_raytracer_amd import _capi
+
+    path = ROOT / "profiles" / name
+    if not path.exists():
+        return None, f"no profiles/{name}"
+    try:
+        rec = json.loads(path.read_text())
+    except Exception as exc:  # noqa: BLE001
+        return None, f"profiles/{name}: {exc}"
+    for k, v in match.items():
+        if rec.get(k, v if k == "variant" and v == 2 else None) != v:
+            return None, f"profiles/{name} is a profile of another workload ({k} = {rec.get(k)!r}, this run {v!r})"
+    if rec.get("sources_sha256") != _capi.sources_sha256():
+        return None, f"profiles/{name} was collected with other kernel sources (sha256 {str(rec.get('sources_sha256'))[:12]}..., this tree {_capi.sources_sha256()[:12]}...): re-run tools/profile_round.sh + tools/make_traffic.py"
+    return rec, None
+
+
 def hbm_view(counter_bytes, alg_bytes, ms, rec):
     """north_star: "achieved HBM GB/s and L2-hit rate".  `achieved` is what HBM SAW — FETCH_SIZE (x2 on gfx950) + WRITE_SIZE of the
     committed rocprofv3 --pmc profile of this very workload, over the live kernel time; the algorithmic bytes sit
@@ -128,6 +150,7 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
     import torch.distributed as dist
 
     import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import _capi
     from homework_18_graphics_raytracer_amd import dist as rtdist
 
     frame = rtdist.shard_frame(width, height, depth, rank, world_size)
@@ -148,6 +171,8 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib = _capi.amd_lib()
+    _capi.check(lib.rt_profile_enable(1))  # an event pair around every kernel of the pass, on the stream it is launched on
     t0 = time.perf_counter()
     e0.record()
     rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, ray_count=cnt)
@@ -159,6 +184,9 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     render_ms = e0.elapsed_time(e1)  # this rank's epochs alone, HIP events on the launch stream
+    k_ms, k_n = (C.c_double * 4)(), (C.c_uint * 4)()
+    _capi.check(lib.rt_profile_read_distributed(k_ms, k_n))
+    _capi.check(lib.rt_profile_enable(0))
     t = torch.tensor([elapsed, render_ms], dtype=torch.float64, device="cuda")
     total = cnt.clone()
     if distributed:
@@ -174,6 +202,12 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
     if world_desc is not None:
         flop_per_cast = world_desc.n_triangles * FLOP_PER_TRIANGLE_TEST + world_desc.n_spheres * FLOP_PER_SPHERE_TEST
     tflops = casts_rank * flop_per_cast / (render_ms * 1e-3) / 1e12
+    # the pass's kernels from this run's own HIP events (rank 0's): each one's summed duration under the overlap of a pipelined call
+    names = ("rng look-ahead (rng_scan + rng_prepare)", "dist_chain_kernel", "dist_shade_lights_kernel", "dist_unwind_kernel")
+    k_total = sum(k_ms) or 1.0
+    kernels = {names[i]: {"ms_sum": round(k_ms[i], 3), "launches": int(k_n[i]), "share_of_kernel_time": round(k_ms[i] / k_total, 3)} for i in range(4)}
+    kernel_note = ("the pass's kernels together; live HIP events of this run, summed per kernel (they overlap in a pipelined call, so the sums exceed render_ms): "
+                   + ", ".join(f"{names[i]} {100.0 * k_ms[i] / k_total:.0f} %" for i in sorted(range(4), key=lambda i: -k_ms[i])))
     rank_samples = frame.rows * frame.cols * epochs
     alg_bytes = rank_samples * (12 + 2 * 2064)  # 12 B out + the generator's record read and written, per sample
     out = {"metric": "Msamples/s, depth-of-field pass (one sample = shoot_focus + cast + distributed_ray_trace of one pixel)",
@@ -185,22 +219,16 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
                       "epochs": epochs, "samples": samples},
            "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 4), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tflops / PEAK_FP32_VECTOR_TFLOPS, 5), "traffic": None,
-                        "kernel": "the pass's four kernels together (rng look-ahead, dist_chain_kernel, dist_shade_kernel, dist_unwind_kernel); dist_chain_kernel is ~55 % of it",
+                        "kernel": kernel_note, "kernels": kernels,
                         "render_ms": round(render_ms, 3), "flop_per_cast": flop_per_cast, "casts_per_launch": casts_rank,
                         "note": "algorithmic flop = casts x (T x 77 + S x 28): an upper bound on useful work, as for the Whitted pass"},
            "parity": "tests/test_gpu_distributed_parity.py, tests/test_gpu_reference_pins.py"}
-    rec = None
-    tpath = ROOT / "profiles" / traffic_file
-    if tpath.exists():
-        try:
-            rec = json.loads(tpath.read_text())
-            if not (rec.get("width") == width and rec.get("height") == height and rec.get("depth") == depth and rec.get("epochs") == epochs and world_size == 1):
-                rec = None
-        except Exception:
-            rec = None
+    rec, why = (None, "counter profiles are single-GPU") if world_size != 1 else traffic_record(traffic_file, {"width": width, "height": height, "depth": depth, "epochs": epochs})
     if rec:
         out["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
     out["roofline"]["hbm"] = hbm_view(rec.get("hbm_bytes_per_launch") if rec else None, alg_bytes, render_ms, rec)
+    if why:
+        out["roofline"]["hbm"]["source"] = why
     if world_desc is not None and world_size == 1:
         # the oracle's restatement of the same loop on the host cores: the FIRST epoch of the same frame; the GPU's first
         # epoch (fresh streams, same seeds) must equal it bit for bit
@@ -230,6 +258,106 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
     return out
 
 
+def share_timing(scene, camera, width, height, depth, steps):
+    """What ONE GPU needs for a 1/2, 1/4, 1/8 share of either pass — rank 0's interleaved rows of that many ranks, exactly the
+    frames an N-GPU job gives a rank.  A prediction from one GPU (the critical path of the share's dearest pixels does not shrink
+    with the share), NOT a scaling measurement: the driver's multi-GPU run is that."""
+    import torch
+
+    import homework_18_graphics_raytracer_amd as rt
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+
+    out = {"note": "predicted from one GPU, not a scaling measurement: this GPU's time for rank 0's share of an N-rank job "
+                   "(interleaved rows, no gather); speedup_if_all_ranks_alike = whole frame / share", "shares": {}}
+
+    def whitted_ms(frame):
+        band = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            rt.render_whitted(scene, camera, frame, out=band)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rt.render_whitted(scene, camera, frame, out=band)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / steps
+
+    def dof_ms_per_epoch(frame):
+        accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+        warm = rt.Rng(frame)
+        rt.render_distributed(scene, camera, frame, warm, STOCHASTIC_EPOCHS, accum=accum)
+        torch.cuda.synchronize()
+        warm.close()
+        rng = rt.Rng(frame)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rt.render_distributed(scene, camera, frame, rng, STOCHASTIC_EPOCHS, accum=accum)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3 / STOCHASTIC_EPOCHS
+        rng.close()
+        return dt
+
+    whole = rt.Frame.full(width, height, depth)
+    w1, d1 = whitted_ms(whole), dof_ms_per_epoch(whole)
+    out["whole_frame"] = {"whitted_ms_per_frame": round(w1, 4), "dof_ms_per_epoch": round(d1, 4)}
+    for n in (2, 4, 8):
+        f = rtdist.shard_frame(width, height, depth, 0, n)
+        w, d = whitted_ms(f), dof_ms_per_epoch(f)
+        out["shares"][f"1/{n}"] = {"whitted_ms_per_frame": round(w, 4), "dof_ms_per_epoch": round(d, 4),
+                                    "speedup_if_all_ranks_alike": {"whitted": round(w1 / w, 2), "dof": round(d1 / d, 2)}}
+    return out
+
+
+def sharded_finish(band, height, rank, world_size, distributed, steps):
+    """What follows a frame when its bands stay on their ranks (main.rs:1113-1114 over N ranks): post_process with the p99 luma
+    taken over all ranks (keys -> all-reduce -> 4 x (histogram -> all-reduce -> pick) -> scale, stream-ordered device work),
+    sRGB / u8 encode of each band where it is, ONE gather of u8 rows to rank 0.  Timed per frame like the headline (barrier +
+    synchronize both sides, max over ranks).  With one rank and no process group a single-rank RCCL group is made for the
+    measurement, so that the 1-GPU line already pays for the collectives' launches."""
+    import torch
+    import torch.distributed as dist
+
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+
+    made_group = False
+    out = {"what": "frame -> dist.finish_frame_sharded (post_process over the ranks' bands, sRGB/u8 per band, one u8 gather) -> u8 frame on rank 0",
+           "n_gpus": world_size}
+    try:
+        if not (dist.is_available() and dist.is_initialized()):
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+            made_group = True
+        works = [band.clone() for _ in range(steps + 2)]  # finish normalises its band in place: every step gets the rendered one
+        for k in range(2):
+            rtdist.finish_frame_sharded(works[k], height, rank, world_size, sync=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        u8 = None
+        for k in range(steps):
+            u8, divisor = rtdist.finish_frame_sharded(works[2 + k], height, rank, world_size, sync=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out.update({"ms_per_frame": round(float(t.item()) * 1e3 / steps, 4), "steps": steps, "divisor": float(divisor.item()),
+                    "host_synchronisations_per_frame": 0, "collectives_per_frame": "5 all-reduces (1 + 4 x 256 counters) + 1 gather of u8 rows",
+                    "u8_frame_bytes": int(u8.numel()) if u8 is not None else None,
+                    "process_group": "single-rank RCCL group made for this measurement" if made_group else "the job's"})
+    except Exception as exc:  # noqa: BLE001  (a box without a usable RCCL must not cost the headline)
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    finally:
+        if made_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+    return out
+
+
 def main() -> int:
     args = parse_args()
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,8 +368,9 @@ def main() -> int:
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        __graft_entry__.build()  # no-op when the in-tree libraries are current
+    # every rank, before anything imports the package or touches the GPU: the makes run under a file lock, so one rank builds (a
+    # no-op when the in-tree libraries are current) and the others wait for it instead of loading a library that is being linked
+    __graft_entry__.build()
     import torch
     import torch.distributed as dist
 
@@ -338,23 +467,17 @@ def main() -> int:
         casts_this_rank = int(count.item()) // max(1, args.steps)
         achieved_tflops = casts_this_rank * flop_per_cast / (kernel_ms_max * 1e-3) / 1e12
         alg_hbm_bytes = frame.rows * frame.cols * 12 + 6752  # 12 B/pixel out + the scene once
-        traffic, executed, traffic_rec = None, None, None
-        tpath = ROOT / "profiles" / "traffic.json"
-        if tpath.exists():
-            try:
-                rec = json.loads(tpath.read_text())
-                if rec.get("width") == W and rec.get("height") == H and rec.get("depth") == D and world_size == 1 and rec.get("variant", 2) == variant:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_rec = rec
-                    if rec.get("sq_insts_valu"):
-                        # executed VALU work from the SQ_INSTS_VALU counter of the committed profile (wave-instructions x 64
-                        # lanes), against the issue roof of a path that may not fuse multiply-add: half the FMA peak
-                        lane_ops = float(rec["sq_insts_valu"]) * 64.0
-                        tops = lane_ops / (kernel_ms_max * 1e-3) / 1e12
-                        executed = {"lane_ops_per_launch": lane_ops, "achieved": round(tops, 3), "peak_no_fma": PEAK_FP32_VECTOR_TFLOPS / 2,
-                                    "unit": "T lane-op/s", "frac": round(tops / (PEAK_FP32_VECTOR_TFLOPS / 2), 4), "source": rec.get("source")}
-            except Exception:
-                traffic, executed = None, None
+        traffic, executed = None, None
+        traffic_rec, traffic_why = (None, "counter profiles are single-GPU") if world_size != 1 else traffic_record("traffic.json", {"width": W, "height": H, "depth": D, "variant": variant})
+        if traffic_rec:
+            traffic = traffic_rec.get("hbm_bytes_per_launch")
+            if traffic_rec.get("sq_insts_valu"):
+                # executed VALU work from the SQ_INSTS_VALU counter of the committed profile (wave-instructions x 64
+                # lanes), against the issue roof of a path that may not fuse multiply-add: half the FMA peak
+                lane_ops = float(traffic_rec["sq_insts_valu"]) * 64.0
+                tops = lane_ops / (kernel_ms_max * 1e-3) / 1e12
+                executed = {"lane_ops_per_launch": lane_ops, "achieved": round(tops, 3), "peak_no_fma": PEAK_FP32_VECTOR_TFLOPS / 2,
+                            "unit": "T lane-op/s", "frac": round(tops / (PEAK_FP32_VECTOR_TFLOPS / 2), 4), "source": traffic_rec.get("source")}
         line = {
             "metric": "Mrays/s (primary+secondary) at 1920x1080, depth 8",
             "value": round(mrays, 3),
@@ -401,6 +524,8 @@ def main() -> int:
                 "hbm": hbm_view(traffic, alg_hbm_bytes, kernel_ms_max, traffic_rec),
             },
         }
+        if traffic_why:
+            line["roofline"]["hbm"]["source"] = traffic_why
         if not args.no_cpu_baseline and world_size == 1:
             gpu_frame = full.cpu().numpy() if full is not None else None
             line["cpu_baseline"] = cpu_baseline(desc, camera, W, H, D, args.cpu_threads, gpu_frame)
@@ -463,8 +588,18 @@ def main() -> int:
     if not args.no_stochastic:
         scatter = stochastic_pass(scene, camera, W, H, D, rank, world_size, distributed, world_desc=None, epochs=SCATTER_EPOCHS,
                                   config="configs[4], the scatter pass", traffic_file="traffic_scatter.json")
+    # after everything else: what the frame costs AFTER rendering when its bands stay sharded, and what a share of either pass costs
+    finish, shares = None, None
+    if not args.no_extras:
+        finish = sharded_finish(band if not distributed else pipe.band(0), H, rank, world_size, distributed, min(args.steps, 20))
+        if world_size == 1 and not distributed:
+            shares = share_timing(scene, camera, W, H, D, min(args.steps, 20))
     status = 0
     if rank == 0:
+        if finish is not None:
+            line["sharded_finish"] = finish
+        if shares is not None:
+            line["share_timing"] = shares
         if pipelined is not None:
             line["pipelined"] = pipelined
         if stochastic is not None:

@@ -25,7 +25,7 @@ from ._capi import Camera, Frame, Light, Material, RtError, SceneDesc, Sphere, T
 
 __all__ = [
     "World", "ObjectProxy", "Scene", "Camera", "Frame", "Material", "Light", "RtError", "reference_world",
-    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "render_distributed_numpy", "post_process_device", "encode_srgb8_device", "post_process", "encode_srgb8", "write_to_file",
+    "reference_camera", "render_whitted", "render_whitted_numpy", "Rng", "render_distributed", "render_distributed_numpy", "set_option", "options", "post_process_device", "encode_srgb8_device", "post_process", "encode_srgb8", "write_to_file",
     "DEFAULT_OBJ",
 ]
 
@@ -254,6 +254,29 @@ def render_distributed_numpy(scene: Scene, camera: Camera, frame: Frame, rng: Rn
     _capi.check(_capi.amd_lib().rt_render_distributed_host(scene._h, C.byref(camera), C.byref(frame), float(focus), float(blur), rng._h,
                                                            int(n_epochs), img.ctypes.data_as(C.c_void_p), C.byref(casts)))
     return int(casts.value)
+
+
+def set_option(name: str, value=None) -> None:
+    """A process-wide switch of librt_amd.so (include/rt_amd.h rt_set_option): an integer named like the environment variable that
+    seeds it (the environment is read once per process); None unsets it.  None of them changes a result."""
+    _capi.check(_capi.amd_lib().rt_set_option(name.encode(), None if value is None else str(int(value)).encode()))
+
+
+class options:
+    """`with rt.options(RT_AMD_DIST_PIPELINE=0, RT_AMD_DIST_WS_MB=16): ...` — switches set for the block, unset after it."""
+
+    def __init__(self, **switches):
+        self._switches = switches
+
+    def __enter__(self):
+        for k, v in self._switches.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self._switches:
+            set_option(k, None)
+        return False
 
 
 def post_process_device(img, divisor=None, stream=None):

@@ -122,11 +122,26 @@ class Frame(C.Structure):
 # every symbol include/rt_amd.h declares (checked by tests/test_capi_symbols.py)
 DEFAULT_VARIANT = 18  # RT_VARIANT_PWF | RT_VARIANT_STATIC (csrc/rt_kernels.h)
 
+def sources_sha256() -> str:
+    """One hash over the sources librt_amd.so is built from (csrc/*.hip, *.h, *.inc, the Makefile), in name order.  The committed
+    counter profiles (profiles/traffic*.json, tools/make_traffic.py) carry the hash of the sources they were taken with; bench.py
+    reports counter-based figures only while it equals this one — a kernel change without a fresh profile reads as `null`, not as a
+    stale number."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = PKG_DIR / "csrc"
+    for f in sorted(list(src.glob("*.hip")) + list(src.glob("*.h")) + list(src.glob("*.inc")) + [src / "Makefile"]):
+        h.update(f.name.encode() + b"\0")
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 AMD_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_set_device", "rt_frame_rows", "rt_frame_pixels",
-    "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_variant",
-    "rt_get_variant", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_math_eval_host", "rt_math_eval_device", "rt_scene_describe_nodes", "rt_rng_state_words", "rt_rng_create",
-    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_multi_create", "rt_multi_destroy", "rt_multi_render_whitted_host", "rt_multi_render_distributed_host", "rt_multi_render_whitted", "rt_multi_render_distributed", "rt_post_process_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
+    "rt_scene_create", "rt_scene_destroy", "rt_render_whitted", "rt_render_whitted_host", "rt_set_option", "rt_set_variant",
+    "rt_get_variant", "rt_set_wavefront_budget", "rt_set_distributed_split", "rt_profile_enable", "rt_profile_read", "rt_profile_read_distributed", "rt_math_eval_host", "rt_math_eval_device", "rt_scene_describe_nodes", "rt_rng_state_words", "rt_rng_create",
+    "rt_rng_destroy", "rt_rng_download", "rt_render_distributed", "rt_render_distributed_host", "rt_multi_create", "rt_multi_destroy", "rt_multi_render_whitted_host", "rt_multi_render_distributed_host", "rt_multi_render_whitted", "rt_multi_render_distributed", "rt_post_process_device", "rt_post_keys_device", "rt_post_hist_device", "rt_post_pick_device", "rt_post_scale_device", "rt_post_release", "rt_encode_srgb8_device", "rt_accumulate_device", "rt_accumulator_resolve_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_new", "rt_world_free", "rt_world_push_object", "rt_world_push_triangle", "rt_world_push_sphere",
@@ -206,6 +221,7 @@ def amd_lib() -> C.CDLL:
         lib.rt_render_whitted.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_render_whitted_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_ulonglong)]
         lib.rt_set_variant.argtypes = [C.c_int]
+        lib.rt_set_option.argtypes = [C.c_char_p, C.c_char_p]
         lib.rt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         lib.rt_multi_destroy.argtypes = [C.c_void_p]
         lib.rt_multi_render_whitted_host.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_void_p, C.POINTER(C.c_ulonglong)]
@@ -215,6 +231,10 @@ def amd_lib() -> C.CDLL:
         lib.rt_multi_render_distributed.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame), C.c_float, C.c_float, C.c_uint32,
                                                     C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_post_process_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.rt_post_keys_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.rt_post_hist_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.rt_post_pick_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        lib.rt_post_scale_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_encode_srgb8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rt_accumulate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.rt_accumulator_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

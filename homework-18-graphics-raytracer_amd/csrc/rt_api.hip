@@ -20,8 +20,36 @@ static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
 #endif
 
-thread_local std::string g_error;
-thread_local bool t_prof_off = false; /* rt_api_internal.h ProfilingOff */
+/* the switches of rt_kernels.h `Option`: name (also the environment variable that seeds it), whether it has a value, the value */
+static const char *const OPT_NAMES[rt::OPT_COUNT] = {
+    "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
+    "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
+    "RT_AMD_SHADE_KERNEL", "RT_AMD_SHADE_CAP", "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT"};
+static std::atomic<int> g_opt_set[rt::OPT_COUNT];
+static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
+static std::once_flag g_opt_once;
+static void options_from_environment() {
+    std::call_once(g_opt_once, [] {
+        for (int i = 0; i < rt::OPT_COUNT; ++i) {
+            const char *v = getenv(OPT_NAMES[i]);
+            if (v && *v) {
+                g_opt_val[i].store(strtoll(v, nullptr, 10));
+                g_opt_set[i].store(1);
+            }
+        }
+    });
+}
+namespace rt {
+long long option(Option id, long long unset) {
+    options_from_environment();
+    return g_opt_set[id].load(std::memory_order_acquire) ? g_opt_val[id].load(std::memory_order_relaxed) : unset;
+}
+} /* namespace rt */
+
+static thread_local std::string g_error;
+static thread_local bool t_prof_off = false; /* rt_api_internal.h ProfilingOff */
+std::string &last_error() { return g_error; }
+bool &profiling_off_flag() { return t_prof_off; }
 static std::atomic<int> g_variant{-1};
 
 int fail(int code, const std::string &msg) {
@@ -70,6 +98,9 @@ bool frame_fits(const rt_frame *f) {
     return rows * (uint64_t)(f->x1 - f->x0) < (1ull << 32) - 64u;
 }
 
+static std::atomic<bool> g_prof_on{false}; /* rt_profile_enable */
+bool profiling_on() { return g_prof_on.load() && !t_prof_off; }
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -86,6 +117,25 @@ int rt_device_count(void) {
 int rt_set_device(int device) {
     RT_HIP(hipSetDevice(device));
     return RT_OK;
+}
+
+int rt_set_option(const char *name, const char *value) {
+    if (!name) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_option: null name");
+    options_from_environment(); /* first, so that a later first use does not overwrite what is set here */
+    for (int i = 0; i < rt::OPT_COUNT; ++i) {
+        if (strcmp(name, OPT_NAMES[i]) != 0) continue;
+        if (value && *value) {
+            char *end = nullptr;
+            const long long v = strtoll(value, &end, 10);
+            if (end == value || *end != '\0') return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_option: the value is not an integer");
+            g_opt_val[i].store(v, std::memory_order_relaxed);
+            g_opt_set[i].store(1, std::memory_order_release);
+        } else {
+            g_opt_set[i].store(0, std::memory_order_release);
+        }
+        return RT_OK;
+    }
+    return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_set_option: unknown option ") + name);
 }
 
 int rt_set_variant(int variant) {
@@ -110,13 +160,13 @@ int rt_set_wavefront_budget(unsigned nodes_per_pixel) {
 static std::mutex g_prof_mutex;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static size_t g_prof_used = 0;
-static std::atomic<bool> g_prof_on{false};
 
 
 int rt_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof_on.store(on != 0);
     g_prof_used = 0;
+    dist_profile_reset();
     rt::set_main_kernel_events(nullptr, nullptr);
     return RT_OK;
 }
@@ -335,8 +385,8 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 ws.d_pwf = nullptr;
                 ws.pwf_bytes = 0;
                 ws.pw_ready = false;
-                const char *refuse = getenv("RT_AMD_DIAG_WS_REFUSE"); /* test hook: pretend the allocation fails */
-                if ((refuse && atoi(refuse) > 0) || hipMalloc(&ws.d_pwf, need) != hipSuccess) {
+                /* OPT_DIAG_WS_REFUSE: test hook, pretend the allocation fails */
+                if (rt::option(rt::OPT_DIAG_WS_REFUSE, 0) > 0 || hipMalloc(&ws.d_pwf, need) != hipSuccess) {
                     (void)hipGetLastError();
                     ws.d_pwf = nullptr;
                 } else {

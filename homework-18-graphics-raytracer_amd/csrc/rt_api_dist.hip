@@ -11,7 +11,56 @@
 static std::atomic<int> g_dist_split{-1}; /* -1: RT_AMD_DIST_SPLIT or the default */
 extern "C" int rt_set_distributed_split(int on) { g_dist_split.store(on < 0 ? -1 : (on > 1 ? 1 : on)); return 0; } /* 2 (round 2's queued chain) is 1 now */
 
+/* ---- timing of the pass's kernels (rt_profile_enable / rt_profile_read_distributed): while profiling is on, every launch is
+ * bracketed by an event pair on the stream it is put on — kernels of a pipelined call overlap, so the per-kernel sums add up to
+ * more than the call takes; what they give is each kernel's own duration under that overlap (what rocprofv3 --kernel-trace shows) */
+enum { DK_PREPARE = 0, DK_CHAIN, DK_SHADE, DK_UNWIND, DK_KINDS };
+struct DistProfile {
+    std::mutex mutex;
+    std::vector<hipEvent_t> events; /* pairs */
+    std::vector<int> kind;          /* per pair */
+    size_t used = 0;                /* pairs */
+};
+static DistProfile g_dprof;
+void dist_profile_reset() {
+    std::lock_guard<std::mutex> lock(g_dprof.mutex);
+    g_dprof.used = 0;
+}
+/* n pairs of consecutive kinds starting at `kind`; false (and no events) when profiling is off or events cannot be made */
+static bool dist_profile_pairs(int kind, int n, hipEvent_t *out) {
+    if (!profiling_on()) return false;
+    std::lock_guard<std::mutex> lock(g_dprof.mutex);
+    while (g_dprof.events.size() < 2u * (g_dprof.used + (size_t)n)) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return false; }
+        g_dprof.events.push_back(e);
+    }
+    g_dprof.kind.resize(g_dprof.events.size() / 2u);
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = g_dprof.events[2u * (g_dprof.used + (size_t)i)];
+        out[2 * i + 1] = g_dprof.events[2u * (g_dprof.used + (size_t)i) + 1u];
+        g_dprof.kind[g_dprof.used + (size_t)i] = kind + i;
+    }
+    g_dprof.used += (size_t)n;
+    return true;
+}
+
 extern "C" {
+
+int rt_profile_read_distributed(double ms_sum[4], unsigned n_launches[4]) {
+    if (!ms_sum || !n_launches) return fail(RT_ERR_INVALID_ARGUMENT, "rt_profile_read_distributed: null argument");
+    RT_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_dprof.mutex);
+    for (int k = 0; k < DK_KINDS; ++k) { ms_sum[k] = 0.0; n_launches[k] = 0u; }
+    for (size_t i = 0; i < g_dprof.used; ++i) {
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, g_dprof.events[2u * i], g_dprof.events[2u * i + 1u]));
+        ms_sum[g_dprof.kind[i]] += ms;
+        n_launches[g_dprof.kind[i]] += 1u;
+    }
+    g_dprof.used = 0;
+    return RT_OK;
+}
 
 /* ---- distributed pass ------------------------------------------------------- */
 
@@ -139,7 +188,11 @@ static hipError_t lookahead_after_chain(void *ctx) {
     rt_rng *rng = static_cast<rt_rng *>(ctx);
     hipError_t e = hipEventRecord(rng->ev_chain, rng->main_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(rng->aux, rng->ev_chain, 0);
+    hipEvent_t pe[2];
+    const bool prof = dist_profile_pairs(DK_PREPARE, 1, pe);
+    if (e == hipSuccess && prof) e = hipEventRecord(pe[0], rng->aux);
     if (e == hipSuccess) e = rt::launch_rng_prepare(rng->d_states, rng->cols * rng->rows, rng->d_list, rng->compute_units, rng->aux);
+    if (e == hipSuccess && prof) e = hipEventRecord(pe[1], rng->aux);
     if (e == hipSuccess) e = hipEventRecord(rng->ev_prepared, rng->aux);
     if (e == hipSuccess) rng->ahead = true;
     return e;
@@ -171,16 +224,12 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
     int split = g_dist_split.load();
-    if (split < 0) {
-        const char *v = getenv("RT_AMD_DIST_SPLIT");
-        split = v && *v ? (*v == '0' ? 0 : (*v == '1' ? 1 : 2)) : RT_DIST_SPLIT_DEFAULT;
-    }
+    if (split < 0) split = rt::option(rt::OPT_DIST_SPLIT, RT_DIST_SPLIT_DEFAULT) != 0 ? 1 : 0;
     const size_t n_pixels = (size_t)kf.cols * kf.rows;
     if (n_pixels == 0 || n_epochs == 0) return RT_OK;
-    bool lookahead = true; /* A/B: RT_AMD_RNG_LOOKAHEAD=0 leaves every IsaacCore::generate to the render kernels */
-    if (const char *v = getenv("RT_AMD_RNG_LOOKAHEAD")) lookahead = !(*v == '0');
-    bool overlap = true; /* A/B: RT_AMD_RNG_OVERLAP=0 runs the look-ahead in line, before each chain kernel */
-    if (const char *v = getenv("RT_AMD_RNG_OVERLAP")) overlap = !(*v == '0');
+    /* the switches (rt_kernels.h Option; rt_set_option or, once per process, the environment) */
+    const bool lookahead = rt::option(rt::OPT_RNG_LOOKAHEAD, 1) != 0; /* 0 leaves every IsaacCore::generate to the render kernels */
+    const bool overlap = rt::option(rt::OPT_RNG_OVERLAP, 1) != 0;     /* 0 runs the look-ahead in line, before each chain kernel */
     rt_scene *mut = const_cast<rt_scene *>(scene);
     if (split && kf.max_depth <= 254) {
         /* chain / shade / unwind kernels over batches of epochs (rt_distributed.hip "the split pass"); a batch is as
@@ -191,20 +240,14 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
         /* Two workspaces, used in turn, when the call has more than one batch: batch k's shade and unwind kernels then run on a
          * stream of their own beside batch k+1's chain kernel (A/B: RT_AMD_DIST_PIPELINE=0: one workspace, everything in line) */
-        bool pipeline = true;
-        if (const char *v = getenv("RT_AMD_DIST_PIPELINE")) pipeline = !(*v == '0');
+        const bool pipeline = rt::option(rt::OPT_DIST_PIPELINE, 1) != 0;
         /* the chain kernel's pixels grouped by cost when a lane gets two of them at most (rt_kernels.h DistParams::pixel_order);
          * A/B: RT_AMD_DIST_BY_COST=0 never, =1 always */
-        bool by_cost = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves);
-        if (const char *v = getenv("RT_AMD_DIST_BY_COST")) by_cost = !(*v == '0');
-        dp.own_first_chunk = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves) ? 1u : 0u; /* rt_kernels.h */
-        if (const char *v = getenv("RT_AMD_DIST_OWN_FIRST")) dp.own_first_chunk = *v == '0' ? 0u : 1u; /* A/B */
-        bool prep_first = true; /* A/B: RT_AMD_DIST_PREP_FIRST=0: shade kernel and look-ahead start together */
-        if (const char *v = getenv("RT_AMD_DIST_PREP_FIRST")) prep_first = !(*v == '0');
-        size_t cap = (size_t)(pipeline ? 32768 : 16384) << 20;
-        if (const char *v = getenv("RT_AMD_DIST_WS_MB")) {
-            if (*v) cap = (size_t)strtoull(v, nullptr, 10) << 20;
-        }
+        const bool small_share = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves);
+        const bool by_cost = rt::option(rt::OPT_DIST_BY_COST, small_share ? 1 : 0) != 0;
+        dp.own_first_chunk = rt::option(rt::OPT_DIST_OWN_FIRST, small_share ? 1 : 0) != 0 ? 1u : 0u; /* rt_kernels.h */
+        const bool prep_first = rt::option(rt::OPT_DIST_PREP_FIRST, 1) != 0; /* 0: shade kernel and look-ahead start together */
+        const size_t cap = (size_t)std::max<long long>(0, rt::option(rt::OPT_DIST_WS_MB, pipeline ? 32768 : 16384)) << 20;
         uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
         if (pipeline && batch < n_epochs) /* more than one batch: each workspace gets half the cap */
             batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / 2u / per_epoch));
@@ -245,8 +288,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                     ws.split_bytes = 0;
                 }
                 /* no room for the batch the cap allows: halve it; no room for one epoch: the one-kernel organisation */
-                int refuse = 0; /* test hook: pretend the first n allocations fail (tests/test_gpu_distributed_parity.py) */
-                if (const char *v = getenv("RT_AMD_DIAG_WS_REFUSE")) refuse = atoi(v);
+                int refuse = (int)rt::option(rt::OPT_DIAG_WS_REFUSE, 0); /* test hook: pretend the first n allocations fail (tests/test_gpu_distributed_parity.py) */
                 while (refuse-- > 0 || hipMalloc(&ws.d_split, need) != hipSuccess) {
                     (void)hipGetLastError();
                     ws.d_split = nullptr;
@@ -279,15 +321,26 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             dp.n_epochs = std::min(batch, n_epochs - e0);
             e = hipMemsetAsync(dp.work_queue, 0, sizeof(uint32_t), stream);
             if (e == hipSuccess && tail_used[b]) e = hipStreamWaitEvent(stream, rng->ev_tail[b], 0); /* the unwind two batches ago has read this workspace */
-            if (e == hipSuccess && lookahead && !rng->ahead) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
+            hipEvent_t pe[8]; /* profiling: prepare | chain | shade, unwind */
+            if (e == hipSuccess && lookahead && !rng->ahead) {
+                const bool prof = dist_profile_pairs(DK_PREPARE, 1, pe);
+                if (prof) e = hipEventRecord(pe[0], stream);
+                if (e == hipSuccess) e = rt::launch_rng_prepare(rng->d_states, (uint32_t)n_pixels, rng->d_list, rng->compute_units, stream);
+                if (e == hipSuccess && prof) e = hipEventRecord(pe[1], stream);
+            }
             rng->ahead = false; /* the chain kernel uses blocks up */
+            const bool prof_chain = dist_profile_pairs(DK_CHAIN, 1, pe + 2);
+            const bool prof_tail = dist_profile_pairs(DK_SHADE, 2, pe + 4);
+            const hipEvent_t *const tail_ev = prof_tail ? pe + 4 : nullptr;
             rng->main_stream = stream;
             /* the pixels in the order of what they cost in the batch that used this workspace last (two batches ago in a pipelined
              * call, the last one else): rt_kernels.h DistParams::pixel_order */
             uint32_t *const pix_cost = rng->d_pix, *const pix_order = rng->d_pix + (size_t)(1u + b) * n_pixels, *const pix_scratch = rng->d_pix + 3u * n_pixels;
             dp.pixel_cost = by_cost ? pix_cost : nullptr;
             dp.pixel_order = by_cost && rng->order_valid[b] ? pix_order : nullptr;
+            if (e == hipSuccess && prof_chain) e = hipEventRecord(pe[2], stream);
             if (e == hipSuccess) e = rt::launch_dist_chain(scene->ks, kf, dp, dist_waves, stream);
+            if (e == hipSuccess && prof_chain) e = hipEventRecord(pe[3], stream);
             /* from here on this batch does not touch the RNG records: the look-ahead for the next one, on its own stream */
             if (e == hipSuccess && lookahead && overlap) e = lookahead_after_chain(rng);
             if (n_buf == 2u) {
@@ -297,7 +350,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                  * kernel starts after it instead of taking that LDS first (between two chain kernels of a 1/8 share of the 1080p
                  * frame 1.1 -> 0.3 ms: 0.38 -> 0.365 ms per epoch, a 1/4 share 0.553 -> 0.517, the whole frame 1.685 -> 1.669) */
                 if (e == hipSuccess && prep_first && rng->ahead) e = hipStreamWaitEvent(rng->tail, rng->ev_prepared, 0);
-                if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, rng->tail);
+                if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, rng->tail, tail_ev);
                 if (e == hipSuccess && by_cost) {
                     e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, rng->tail);
                     rng->order_valid[b] = e == hipSuccess;
@@ -305,7 +358,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                 if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], rng->tail); /* ... then: and the unwind has read it */
                 tail_used[b] = e == hipSuccess;
             } else if (e == hipSuccess) {
-                e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, stream);
+                e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, stream, tail_ev);
                 if (e == hipSuccess && by_cost) {
                     e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, stream);
                     rng->order_valid[b] = e == hipSuccess;
@@ -325,8 +378,7 @@ one_kernel:
     dp.epoch0 = 0;
     dp.sp_hdr = nullptr; dp.sp_req = nullptr; dp.sp_shade = nullptr; dp.sp_frame = nullptr; dp.sp_slots = 0;
     {
-        const char *v = getenv("RT_AMD_DIST_STATIC"); /* A/B: one 64-pixel chunk per wave instead of persistent lanes */
-        if (!(v && *v == '1')) {
+        if (rt::option(rt::OPT_DIST_STATIC, 0) != 1) { /* 1 (A/B): one 64-pixel chunk per wave instead of persistent lanes */
             std::lock_guard<std::mutex> lock(mut->ws_mutex);
             Workspace &ws = mut->workspaces[stream];
             if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));

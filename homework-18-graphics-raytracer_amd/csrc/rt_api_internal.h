@@ -64,7 +64,10 @@ struct rt_scene {
     std::map<hipStream_t, Workspace> workspaces;
 };
 
-extern RT_API_HIDDEN thread_local std::string g_error; /* rt_last_error() of the calling thread */
+/* rt_last_error() of the calling thread.  (Thread-local state is reached through functions of the translation unit that defines
+ * it: an `extern thread_local` of hidden visibility makes the other units call its weak, undefined initialisation function through
+ * a PC-relative address that is not null — a jump to the library's first byte.) */
+RT_API_HIDDEN std::string &last_error();
 RT_API_HIDDEN int fail(int code, const std::string &msg);
 RT_API_HIDDEN int fail_hip(const char *what, hipError_t e);
 #define RT_HIP(call)                                          \
@@ -79,12 +82,17 @@ RT_API_HIDDEN int make_kernel_frame(const rt_camera *camera, const rt_frame *fra
 
 /* the profiling events live on the device that was current when they were made: calls that hop between devices (rt_multi_*) are
  * not profiled (the thread-local switch is theirs) */
-extern RT_API_HIDDEN thread_local bool t_prof_off;
+RT_API_HIDDEN bool &profiling_off_flag(); /* of the calling thread */
 struct ProfilingOff {
     bool prev;
-    ProfilingOff() : prev(t_prof_off) { t_prof_off = true; }
-    ~ProfilingOff() { t_prof_off = prev; }
+    ProfilingOff() : prev(profiling_off_flag()) { profiling_off_flag() = true; }
+    ~ProfilingOff() { profiling_off_flag() = prev; }
 };
+
+/* rt_profile_enable also times the depth-of-field pass's kernels (rt_api_dist.hip): is it on for this thread's calls, and the hooks
+ * rt_profile_enable / rt_profile_read_distributed are made of */
+RT_API_HIDDEN bool profiling_on();
+RT_API_HIDDEN void dist_profile_reset();
 
 /* Everything rt_scene_create derives from the ABI arrays, on the host (no HIP call in there): the device records of
  * rt_device_scene.h.  Also behind rt_scene_describe_nodes, which lets a test look at the node array without a GPU. */

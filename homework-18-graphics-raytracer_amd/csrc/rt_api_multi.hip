@@ -112,9 +112,9 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices
     }
     (void)hipSetDevice(prev);
     if (rc != RT_OK) {
-        const std::string msg = g_error;
+        const std::string msg = last_error();
         (void)rt_multi_destroy(m);
-        g_error = msg;
+        last_error() = msg;
         return rc;
     }
     *out = m;
@@ -145,7 +145,7 @@ static int multi_prepare(rt_multi *m, const rt_frame *frame, std::vector<rt_fram
             e = hipHostMalloc(reinterpret_cast<void **>(&p.h_band), floats * sizeof(float), hipHostMallocDefault);
             if (e == hipSuccess) p.h_floats = floats;
         }
-        if (e == hipSuccess && !host_bands && floats > p.stage_floats && (p.device != m->parts[0].device || getenv("RT_AMD_MULTI_FORCE_STAGE") != nullptr)) {
+        if (e == hipSuccess && !host_bands && floats > p.stage_floats && (p.device != m->parts[0].device || rt::option(rt::OPT_MULTI_FORCE_STAGE, 0) != 0)) {
             e = hipSetDevice(m->parts[0].device);
             if (e == hipSuccess && p.d_stage) (void)hipFree(p.d_stage);
             p.d_stage = nullptr;

@@ -67,6 +67,39 @@ int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void
     return RT_OK;
 }
 
+/* the passes of rt_post_process_device one by one, on the caller's device memory (include/rt_amd.h) */
+int rt_post_keys_device(const float *d_rgb, size_t n_pixels, uint32_t *d_keys, uint32_t *d_state, void *hip_stream) {
+    if (!d_state || (n_pixels && (!d_rgb || !d_keys))) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_keys_device: null argument");
+    float row[3];
+    rt::luma_row(row);
+    const hipError_t e = rt::launch_post_keys(d_rgb, n_pixels, row, d_keys, d_state, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_post_keys_device: launch", e);
+    return RT_OK;
+}
+
+int rt_post_hist_device(const uint32_t *d_keys, size_t n_pixels, int pass, uint32_t *d_state, void *hip_stream) {
+    if (!d_state || (n_pixels && !d_keys)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_hist_device: null argument");
+    if (pass < 0 || pass > 3) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_hist_device: pass 0..3");
+    const hipError_t e = rt::launch_post_hist(d_keys, n_pixels, pass, d_state, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_post_hist_device: launch", e);
+    return RT_OK;
+}
+
+int rt_post_pick_device(int pass, uint32_t *d_state, void *hip_stream) {
+    if (!d_state) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_pick_device: null argument");
+    if (pass < 0 || pass > 3) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_pick_device: pass 0..3");
+    const hipError_t e = rt::launch_post_pick(pass, d_state, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_post_pick_device: launch", e);
+    return RT_OK;
+}
+
+int rt_post_scale_device(float *d_rgb, size_t n_pixels, const uint32_t *d_state, float *d_divisor, void *hip_stream) {
+    if (!d_state || (n_pixels && !d_rgb)) return fail(RT_ERR_INVALID_ARGUMENT, "rt_post_scale_device: null argument");
+    const hipError_t e = rt::launch_post_scale(d_rgb, n_pixels, d_state, d_divisor, static_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail_hip("rt_post_scale_device: launch", e);
+    return RT_OK;
+}
+
 int rt_accumulate_device(const float *d_samples, const unsigned char *d_valid, uint32_t n_epochs, size_t n_pixels, float *d_sum,
                          float *d_weight, void *hip_stream) {
     if (!d_samples || !d_valid || !d_sum || !d_weight) return fail(RT_ERR_INVALID_ARGUMENT, "rt_accumulate_device: null argument");

@@ -75,6 +75,29 @@ struct KernelQueues {
     const uint32_t *run_if;        /* when set: the kernel is a no-op unless *run_if != 0 (the persistent-wavefront path's overflow fallback) */
 };
 
+/* Process-wide switches — A/B knobs and test hooks (include/rt_amd.h rt_set_option).  Each is an integer that starts from the
+ * environment variable of its name, read ONCE per process at the first use of any of them, and can be changed at run time through
+ * rt_set_option; option() returns `unset` while it has no value.  (Defined in rt_api.hip; OPT_NAMES there is in this order.) */
+enum Option : int {
+    OPT_RNG_LOOKAHEAD,     /* 0: every IsaacCore::generate is left to the render kernels */
+    OPT_RNG_OVERLAP,       /* 0: the look-ahead runs in line, before each chain kernel */
+    OPT_DIST_PIPELINE,     /* 0: one workspace, a batch's kernels in line */
+    OPT_DIST_BY_COST,      /* the chain kernel's pixels grouped by cost: 0 never, 1 always (unset: by the share's size) */
+    OPT_DIST_OWN_FIRST,    /* a wave's first chunk its own: 0 / 1 (unset: by the share's size) */
+    OPT_DIST_PREP_FIRST,   /* 0: the shade kernel and the look-ahead start together */
+    OPT_DIST_WS_MB,        /* cap of the split pass's workspace(s), MiB */
+    OPT_DIAG_WS_REFUSE,    /* test hook: pretend the first n workspace allocations fail */
+    OPT_DIST_STATIC,       /* 1: the one-kernel organisation with one 64-pixel chunk per wave */
+    OPT_DIST_CHAIN_WAVES,  /* waves per SIMD of the chain kernel's grid */
+    OPT_SHADE_TILE, OPT_SHADE_SORT, /* the per-request shade kernel: samples per workgroup; 0: no bucket sort */
+    OPT_SHADE_KERNEL,      /* 0: the per-request light loop instead of the lights as phases */
+    OPT_SHADE_CAP,         /* requests per round of the lights-as-phases kernel */
+    OPT_MULTI_FORCE_STAGE, /* test hook: rt_multi_* stage every band as if it lived on another device */
+    OPT_DIST_SPLIT,        /* 0: the one-kernel organisation (rt_set_distributed_split has the last word) */
+    OPT_COUNT
+};
+long long option(Option id, long long unset);
+
 void set_main_kernel_events(hipEvent_t start, hipEvent_t stop); /* profiling hook, see rt_profile_* */
 void record_main_kernel_event(int which, hipStream_t stream);    /* 0: start, 1: stop; no-op when profiling is off */
 void mute_main_kernel_events(bool muted);                        /* launches in between are not the render kernel */
@@ -158,13 +181,19 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
  * the look-ahead for the next batch, and the next batch's chain kernel on another workspace, beside them */
 uint32_t dist_chain_waves(uint32_t resident_waves); /* the chain kernel's grid, at most */
 hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
-hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream);
+hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream,
+                                    const hipEvent_t *ev = nullptr); /* ev: four events of the caller's, recorded around the shade kernel and around the unwind */
 /* order[] <- the pixels 0 .. n-1 grouped by cost[] (clipped to 255), dearest first; scratch: 512 words */
 hipError_t launch_dist_pixel_order(const uint32_t *cost, uint32_t *order, uint32_t n_pixels, uint32_t *scratch, hipStream_t stream);
 
 /* post_process / sRGB encode on the device (rt_post.hip) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,
                                float *divisor_out, hipStream_t stream);
+/* its passes one by one (rt_post.hip): keys n_pixels u32, state RT_POST_STATE_WORDS u32, both the caller's */
+hipError_t launch_post_keys(const float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state, hipStream_t stream);
+hipError_t launch_post_hist(const uint32_t *keys, size_t n_pixels, int pass, uint32_t *state, hipStream_t stream);
+hipError_t launch_post_pick(int pass, uint32_t *state, hipStream_t stream);
+hipError_t launch_post_scale(float *rgb, size_t n_pixels, const uint32_t *state, float *divisor_out, hipStream_t stream);
 hipError_t launch_encode_srgb8(const float *rgb, size_t n_values, unsigned char *out, hipStream_t stream);
 hipError_t launch_accumulate(const float *samples, const unsigned char *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight,
                              hipStream_t stream);

@@ -152,21 +152,47 @@ static unsigned grid_for(size_t n) {
     return (unsigned)b;
 }
 
-/* keys: n_pixels u32; state: 260 u32 (zeroed here) */
+/* The passes one by one, on caller-owned memory (keys: n_pixels u32; state: RT_POST_STATE_WORDS u32) — so that a frame whose bands
+ * live on several ranks can sum `state` over them between the passes (dist.post_process_sharded: all-reduce of state[0] after the
+ * keys, of state[4..259] after each histogram) with everything stream-ordered and no host round trip:
+ *   keys   zeroes state; keys[i] <- order key of pixel i's luma; state[0] <- this band's count of normal lumas
+ *   hist   (pass 0 first turns state[0] — by now the count over all bands — into the rank wanted, main.rs:754) state[4..259] += the
+ *          histogram of this band's keys that match the prefix chosen so far
+ *   pick   the digit of the wanted rank from the (summed) histogram; clears it
+ *   scale  divide by the selected luma when it is above f32::EPSILON (main.rs:755-760) */
+hipError_t launch_post_keys(const float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(state, 0, 260 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if (n_pixels != 0)
+        hipLaunchKernelGGL(post_keys_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, rgb, keys, n_pixels, luma_row[0], luma_row[1],
+                           luma_row[2], state);
+    return hipGetLastError();
+}
+hipError_t launch_post_hist(const uint32_t *keys, size_t n_pixels, int pass, uint32_t *state, hipStream_t stream) {
+    if (pass == 0) hipLaunchKernelGGL(post_rank_kernel, dim3(1), dim3(1), 0, stream, state);
+    if (n_pixels != 0) hipLaunchKernelGGL(post_hist_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, keys, n_pixels, pass, state);
+    return hipGetLastError();
+}
+hipError_t launch_post_pick(int pass, uint32_t *state, hipStream_t stream) {
+    hipLaunchKernelGGL(post_pick_kernel, dim3(1), dim3(64), 0, stream, pass, state);
+    return hipGetLastError();
+}
+hipError_t launch_post_scale(float *rgb, size_t n_pixels, const uint32_t *state, float *divisor_out, hipStream_t stream) {
+    hipLaunchKernelGGL(post_scale_kernel, dim3(grid_for(n_pixels * 3)), dim3(256), 0, stream, rgb, n_pixels * 3, state, divisor_out);
+    return hipGetLastError();
+}
+
+/* all of it on one device: keys: n_pixels u32; state: 260 u32 (zeroed here) */
 hipError_t launch_post_process(float *rgb, size_t n_pixels, const float luma_row[3], uint32_t *keys, uint32_t *state,
                                float *divisor_out, hipStream_t stream) {
     if (n_pixels == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(state, 0, 260 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(post_keys_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, rgb, keys, n_pixels, luma_row[0], luma_row[1],
-                       luma_row[2], state);
-    hipLaunchKernelGGL(post_rank_kernel, dim3(1), dim3(1), 0, stream, state);
-    for (int pass = 0; pass < 4; ++pass) {
-        hipLaunchKernelGGL(post_hist_kernel, dim3(grid_for(n_pixels)), dim3(256), 0, stream, keys, n_pixels, pass, state);
-        hipLaunchKernelGGL(post_pick_kernel, dim3(1), dim3(64), 0, stream, pass, state);
+    hipError_t e = launch_post_keys(rgb, n_pixels, luma_row, keys, state, stream);
+    for (int pass = 0; pass < 4 && e == hipSuccess; ++pass) {
+        e = launch_post_hist(keys, n_pixels, pass, state, stream);
+        if (e == hipSuccess) e = launch_post_pick(pass, state, stream);
     }
-    hipLaunchKernelGGL(post_scale_kernel, dim3(grid_for(n_pixels * 3)), dim3(256), 0, stream, rgb, n_pixels * 3, state, divisor_out);
-    return hipGetLastError();
+    if (e == hipSuccess) e = launch_post_scale(rgb, n_pixels, state, divisor_out, stream);
+    return e;
 }
 
 hipError_t launch_accumulate(const float *samples, const unsigned char *valid, uint32_t n_epochs, size_t n_pixels, float *sum, float *weight,

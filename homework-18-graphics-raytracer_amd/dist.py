@@ -85,7 +85,120 @@ def accumulate_epochs_sharded(render_epochs: Callable[[Frame], "object"], width:
     return gather_frame(render_epochs(frame), height, rank, world, dst=dst, group=group, staging=staging)
 
 
-def post_process_sharded(band, group=None) -> float:
+class _PostPassesHip:
+    """The passes of post_process on THIS rank's band as stream-ordered device work: rt_post_keys_device / rt_post_hist_device /
+    rt_post_pick_device / rt_post_scale_device (include/rt_amd.h, csrc/rt_post.hip) on the current stream.  `count` and `hist`
+    are views of the device-resident state, to be summed over the ranks in place."""
+
+    def __init__(self, band):
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+
+        assert band.is_cuda and band.dtype == torch.float32 and band.is_contiguous() and band.shape[-1] == 3
+        self._C, self._lib, self._check = C, _capi.amd_lib(), _capi.check
+        self.band, self.n = band, band.numel() // 3
+        self.keys = torch.empty(max(self.n, 1), dtype=torch.int32, device=band.device)
+        self.state = torch.empty(260, dtype=torch.int32, device=band.device)  # RT_POST_STATE_WORDS
+        self.divisor = torch.empty(1, dtype=torch.float32, device=band.device)
+        self.count, self.hist = self.state[0:1], self.state[4:260]
+
+    def _stream(self):
+        import torch
+
+        return self._C.c_void_p(torch.cuda.current_stream(self.band.device).cuda_stream)
+
+    def _p(self, t):
+        return self._C.c_void_p(t.data_ptr())
+
+    def do_keys(self):
+        self._check(self._lib.rt_post_keys_device(self._p(self.band), self.n, self._p(self.keys), self._p(self.state), self._stream()))
+
+    def do_hist(self, pass_):
+        self._check(self._lib.rt_post_hist_device(self._p(self.keys), self.n, pass_, self._p(self.state), self._stream()))
+
+    def do_pick(self, pass_):
+        self._check(self._lib.rt_post_pick_device(pass_, self._p(self.state), self._stream()))
+
+    def do_scale(self):
+        self._check(self._lib.rt_post_scale_device(self._p(self.band), self.n, self._p(self.state), self._p(self.divisor), self._stream()))
+        return self.divisor
+
+
+class _PostPassesCpu:
+    """The CPU twin of the same passes for a host-resident band (the gloo tests; a host that keeps its image in memory): the state
+    words mean what csrc/rt_post.hip's mean — [0] count, [1] rank wanted, [2] digits chosen, [4..259] histogram."""
+
+    def __init__(self, band):
+        import torch
+
+        from . import luma_row
+
+        assert not band.is_cuda and band.dtype == torch.float32 and band.shape[-1] == 3
+        self.band = band
+        self.row = [torch.tensor(v, dtype=torch.float32) for v in luma_row()]
+        self.state = torch.zeros(260, dtype=torch.int64)
+        self.count, self.hist = self.state[0:1], self.state[4:260]
+        self.keys = None
+
+    def do_keys(self):
+        import torch
+
+        b, (w0, w1, w2) = self.band, self.row
+        luma = (b[..., 0] * w0 + b[..., 1] * w1) + b[..., 2] * w2  # three separate roundings, in the reference's order
+        bits = luma.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        mag = bits & 0x7FFFFFFF
+        normal = (mag >= 0x00800000) & (mag < 0x7F800000)  # f32::is_normal (main.rs:751)
+        self.keys = torch.where((bits & 0x80000000) != 0, (~bits) & 0xFFFFFFFF, bits | 0x80000000)[normal]  # monotone in the float's value
+        self.state.zero_()
+        self.state[0] = self.keys.numel()
+
+    def do_hist(self, pass_):
+        import numpy as np
+        import torch
+
+        if pass_ == 0:  # (len as f32 * 0.99) as usize, main.rs:754 — of the count over ALL bands
+            n = int(self.state[0])
+            self.state[1] = min(int(np.float32(n) * np.float32(0.99)), max(n - 1, 0))
+            self.state[2] = 0
+        shift = 24 - 8 * pass_
+        prefix = int(self.state[2])
+        sel = self.keys if pass_ == 0 else self.keys[(self.keys >> (shift + 8)) == (prefix >> (shift + 8))]
+        self.hist += torch.bincount((sel >> shift) & 0xFF, minlength=256)
+
+    def do_pick(self, pass_):
+        if int(self.state[0]) == 0:
+            return
+        k, digit = int(self.state[1]), 255
+        for d, c in enumerate(self.hist.tolist()):
+            if k < c:
+                digit = d
+                break
+            k -= c
+        self.state[1] = k
+        self.state[2] = int(self.state[2]) | (digit << (24 - 8 * pass_))
+        self.hist.zero_()
+
+    def do_scale(self):
+        import numpy as np
+        import torch
+
+        zero = torch.zeros(1, dtype=torch.float32)
+        if int(self.state[0]) == 0:
+            return zero
+        key = int(self.state[2])
+        raw = (key & 0x7FFFFFFF) if key & 0x80000000 else (~key) & 0xFFFFFFFF
+        p98 = np.array([raw], dtype=np.uint32).view(np.float32)[0]
+        if not (p98 > np.float32(1.1920928955078125e-7)):  # main.rs:755
+            return zero
+        # a one-element TENSOR divisor: a Python scalar would let torch multiply by the reciprocal (one rounding more than the division)
+        self.band.div_(torch.full((1, 1, 1), float(p98), dtype=torch.float32))
+        return torch.full((1,), float(p98), dtype=torch.float32)
+
+
+def post_process_sharded(band, group=None, sync: bool = True):
     """`post_process` (src/main.rs:748-762) of a frame whose row bands live on the ranks of `group`: divides THIS rank's `band`
     (rows, width, 3 float32; CPU for gloo, CUDA for RCCL) in place by the 99th-percentile luma of ALL ranks' normal lumas and
     returns the divisor (0.0: the frame was left untouched, as the reference does when the percentile is <= f32::EPSILON or no
@@ -93,52 +206,27 @@ def post_process_sharded(band, group=None) -> float:
     own band (encode_srgb8_band) and the gather moves u8, 6.2 MB at 1080p instead of 24.9.
 
     The reference sorts the lumas and indexes one element; the k-th smallest does not depend on the order, so it is found by an
-    exact radix select over order-preserving 32-bit keys — the scheme of csrc/rt_post.hip — whose four 256-bin histograms are
-    summed over the ranks (one all_reduce of 256 counters per pass, one of the count before).  Every rank sees the same
-    histograms, picks the same digit, ends with the same key: the value main.rs:754 indexes.  The arithmetic on the pixels — the
-    luma (w0*r + w1*g) + w2*b, the division — is elementwise IEEE binary32 and therefore the same bits as rt_post_process's."""
-    import numpy as np
-    import torch
+    exact radix select over order-preserving 32-bit keys whose four 256-bin histograms (and, before them, the count) are summed
+    over the ranks.  Every rank sees the same sums, picks the same digits, ends with the same key: the value main.rs:754 indexes.
+
+    A CUDA band never leaves the device and nothing here waits for it: keys -> all_reduce(count) -> 4 x (hist -> all_reduce ->
+    pick) -> scale are kernels of csrc/rt_post.hip on the current stream with RCCL's all-reduces ordered between them, the count,
+    the histogram and the chosen digits in device memory throughout.  `sync=False` returns the divisor as a one-element tensor
+    where the band lives (no host round trip at all); the default reads it (the one synchronisation, when the divisor is wanted)."""
     import torch.distributed as dist
 
-    from . import luma_row
-
     on = dist.is_available() and dist.is_initialized()
-    w0, w1, w2 = (torch.tensor(v, dtype=torch.float32, device=band.device) for v in luma_row())
-    luma = (band[..., 0] * w0 + band[..., 1] * w1) + band[..., 2] * w2  # three separate roundings, in the reference's order
-    bits = luma.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    mag = bits & 0x7FFFFFFF
-    normal = (mag >= 0x00800000) & (mag < 0x7F800000)  # f32::is_normal (main.rs:751)
-    keys = torch.where((bits & 0x80000000) != 0, (~bits) & 0xFFFFFFFF, bits | 0x80000000)[normal]  # monotone in the float's value
-    count = torch.tensor([keys.numel()], dtype=torch.int64, device=band.device)
+    passes = _PostPassesHip(band) if band.is_cuda else _PostPassesCpu(band)
+    passes.do_keys()
     if on:
-        dist.all_reduce(count, group=group)
-    n = int(count.item())
-    if n == 0:
-        return 0.0
-    k = int(np.float32(n) * np.float32(0.99))  # (len as f32 * 0.99) as usize, main.rs:754
-    k = min(k, n - 1)
-    prefix = 0
+        dist.all_reduce(passes.count, group=group)
     for p in range(4):
-        shift = 24 - 8 * p
-        sel = keys if p == 0 else keys[(keys >> (shift + 8)) == (prefix >> (shift + 8))]
-        hist = torch.bincount((sel >> shift) & 0xFF, minlength=256)
+        passes.do_hist(p)
         if on:
-            dist.all_reduce(hist, group=group)
-        digit = 255
-        for d, c in enumerate(hist.tolist()):
-            if k < c:
-                digit = d
-                break
-            k -= c
-        prefix |= digit << shift
-    raw = (prefix & 0x7FFFFFFF) if prefix & 0x80000000 else (~prefix) & 0xFFFFFFFF
-    p98 = np.array([raw], dtype=np.uint32).view(np.float32)[0]
-    if not (p98 > np.float32(1.1920928955078125e-7)):  # main.rs:755
-        return 0.0
-    # a one-element TENSOR divisor: a Python scalar would let torch multiply by the reciprocal (one rounding more than the division)
-    band.div_(torch.full((1, 1, 1), float(p98), dtype=torch.float32, device=band.device))
-    return float(p98)
+            dist.all_reduce(passes.hist, group=group)
+        passes.do_pick(p)
+    divisor = passes.do_scale()
+    return float(divisor.item()) if sync else divisor
 
 
 def encode_srgb8_band(band):
@@ -153,11 +241,12 @@ def encode_srgb8_band(band):
     return torch.from_numpy(encode_srgb8(band.contiguous().numpy()))
 
 
-def finish_frame_sharded(band, height: int, rank: int, world: int, dst: int = 0, group=None, staging=None):
+def finish_frame_sharded(band, height: int, rank: int, world: int, dst: int = 0, group=None, staging=None, sync: bool = True):
     """What main() does with a frame after rendering it (main.rs:1113-1114, 1171-1172), sharded: post_process over the ranks'
     bands, sRGB/u8 encode of each band where it is, then ONE gather of u8 rows to `dst`.  Returns (u8 frame on dst | None, divisor);
-    `band` is left normalised, as the reference leaves `img` — the next epoch accumulates into it."""
-    divisor = post_process_sharded(band, group=group)
+    `band` is left normalised, as the reference leaves `img` — the next epoch accumulates into it.  `sync=False`: the divisor stays
+    a one-element tensor and, for a CUDA band, the whole step is enqueued without the host waiting for any of it."""
+    divisor = post_process_sharded(band, group=group, sync=sync)
     return gather_frame(encode_srgb8_band(band), height, rank, world, dst=dst, group=group, staging=staging), divisor
 
 

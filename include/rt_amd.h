@@ -283,6 +283,24 @@ int rt_post_process_device(float *d_rgb, size_t n_pixels, float *d_divisor, void
 /* rt_post_process_device keeps a grow-only scratch buffer per (device, stream); this frees those of the current device
  * (synchronises it first). */
 int rt_post_release(void);
+/* The same post_process for a frame whose row bands live on SEVERAL ranks or devices (src/main.rs:748-762 needs the 99th
+ * percentile of ALL lumas): the passes of rt_post_process_device one by one on caller-owned device memory — d_keys: n_pixels
+ * u32, d_state: RT_POST_STATE_WORDS u32 — so that the caller can sum d_state over the bands between them (an all-reduce on the
+ * same stream order) and every band ends with the same divisor without a host round trip:
+ *     rt_post_keys_device    zeroes d_state; one order-preserving key per pixel of THIS band; d_state[0] = its count of normal lumas
+ *       -> sum d_state[0] over the bands
+ *     for pass = 0 .. 3:
+ *         rt_post_hist_device   d_state[4 .. 259] += histogram of this band's keys that match the digits chosen so far
+ *           -> sum d_state[4 .. 259] over the bands
+ *         rt_post_pick_device   every band picks the same digit from the same sums (and clears the histogram)
+ *     rt_post_scale_device   divides this band by the selected luma (*d_divisor as for rt_post_process_device)
+ * With one band and no sums in between this IS rt_post_process_device.  The k-th smallest does not depend on the order, so
+ * the value equals the one main.rs:754 indexes after its sort.  Stream-ordered; n_pixels may be 0 (a rank without rows). */
+#define RT_POST_STATE_WORDS 260
+int rt_post_keys_device(const float *d_rgb, size_t n_pixels, uint32_t *d_keys, uint32_t *d_state, void *hip_stream);
+int rt_post_hist_device(const uint32_t *d_keys, size_t n_pixels, int pass, uint32_t *d_state, void *hip_stream);
+int rt_post_pick_device(int pass, uint32_t *d_state, void *hip_stream);
+int rt_post_scale_device(float *d_rgb, size_t n_pixels, const uint32_t *d_state, float *d_divisor, void *hip_stream);
 /* Image::<Srgb<u8>>::convert_from (src/image.rs:55-66): linear f32 -> sRGB-encoded u8, n_values = 3*pixels. */
 int rt_encode_srgb8_device(const float *d_rgb, size_t n_values, unsigned char *d_out, void *hip_stream);
 /* PhotonAccumulator (src/photon.rs:9-34; unused by the reference's main()) on the device, bit-identical to
@@ -306,6 +324,14 @@ int rt_accumulator_resolve_device(const float *d_sum, const float *d_weight, siz
  *   3, 19         as 2 / 18 with the per-pixel kernel's triangle records staged in LDS once per workgroup (the north_star's
  *                 wording; slower than the scalar fetches: DESIGN.md, profiles/)
  * or the value of the RT_AMD_VARIANT environment variable at load.  Anything else is RT_ERR_INVALID_ARGUMENT. */
+/* Process-wide switches: A/B knobs of the launch plumbing and test hooks, none of which changes a result.  Each is an integer
+ * named like the environment variable that seeds it — RT_AMD_DIST_PIPELINE, RT_AMD_DIST_WS_MB, RT_AMD_RNG_LOOKAHEAD,
+ * RT_AMD_RNG_OVERLAP, RT_AMD_DIST_BY_COST, RT_AMD_DIST_OWN_FIRST, RT_AMD_DIST_PREP_FIRST, RT_AMD_DIST_SPLIT, RT_AMD_DIST_STATIC,
+ * RT_AMD_DIST_CHAIN_WAVES, RT_AMD_SHADE_KERNEL, RT_AMD_SHADE_CAP, RT_AMD_SHADE_TILE, RT_AMD_SHADE_SORT, RT_AMD_DIAG_WS_REFUSE,
+ * RT_AMD_MULTI_FORCE_STAGE (INTEGRATION.md says what each does).  The environment is read ONCE per process, at the first use;
+ * after that only this call changes a switch: value = decimal integer, NULL or "" = unset (the library's own choice).  Render
+ * calls read the switches without locks: set them between calls, not during one. */
+int rt_set_option(const char *name, const char *value);
 int rt_set_variant(int variant);
 int rt_get_variant(void);
 
@@ -336,6 +362,12 @@ int rt_set_distributed_split(int on);
  * launches since the last read, and resets. */
 int rt_profile_enable(int on);
 int rt_profile_read(double *kernel_ms_sum, unsigned *n_launches);
+/* The same for the depth-of-field pass: while profiling is enabled, rt_render_distributed (the chain / shade / unwind organisation)
+ * brackets every kernel launch with an event pair on the stream the launch is put on; this synchronises the device and returns, per
+ * kernel — [0] the generators' look-ahead (rng_scan + rng_prepare), [1] dist_chain_kernel, [2] the shade kernel, [3] dist_unwind_kernel —
+ * the summed milliseconds and the launches since the last read, and resets.  Kernels of a pipelined call overlap: these are each
+ * kernel's own durations under that overlap (what a kernel trace shows), not shares of the call's wall time. */
+int rt_profile_read_distributed(double ms_sum[4], unsigned n_launches[4]);
 
 /* The deterministic f32 math the path computes with (csrc/rt_detmath.h),
  * evaluated element-wise on the host or on the device, so tests can prove the

@@ -181,3 +181,49 @@ def squares_world(seed, n_squares=10):
     for i in range(3):
         w.push_light(light(rng, i % 3))
     return w
+
+
+def behind_spot_world(axis=(1.0, 2.0, 3.0), scale=0.37):
+    """A square facing a spot light from BEHIND, seen through a very narrow camera aimed at the point where the light's axis,
+    extended backwards, meets it: for some of those pixels cgmath's `angle` argument dot / (|a| |b|) rounds to just below -1,
+    acos gives NaN, `NaN > spread` is false and the light — pointing the other way — DOES ask, with a NaN colour
+    (lights.rs:57-60).  ADVICE r3: the shortcut of rt_shade.h light_asks must not turn those into None."""
+    w = rt.World()
+    m = Material()
+    m.diffuse_fn = 0
+    m.normal_fn = 0
+    m.normal = (0.0, 0.0, 1.0)
+    m.diffuse_color = (0.8, 0.7, 0.6)
+    m.specular_color = (0.5, 0.5, 0.5)
+    m.shiness, m.smoothness, m.transparency, m.refraction_index, m.opaque_decay = 0.3, 0.2, 0.0, 1.0, 0.0
+    ob = w.push_object(m)
+    o = np.array([0.3, 1.0, -0.2])
+    dn = np.array(axis, float)
+    dn /= np.linalg.norm(dn)
+    c = o - 1.5 * dn
+    a = np.cross(dn, [0, 1, 0])
+    a /= np.linalg.norm(a)
+    b = np.cross(dn, a)
+    corners = [c - 2 * a - 2 * b, c + 2 * a - 2 * b, c + 2 * a + 2 * b, c - 2 * a + 2 * b]
+    ob.push_square([tuple(p) for p in corners], [(0, 0), (0, 1), (1, 0), (0, 1)])
+    spot = Light()
+    spot.kind, spot.has_origin = 1, 1
+    spot.origin = tuple(o)
+    spot.direction = tuple(np.array(axis, float) * scale)
+    spot.angle, spot.softness = 0.9, 1.0
+    spot.color = (1.0, 0.9, 0.8)
+    w.push_light(spot)
+    point = Light()
+    point.kind, point.has_origin = 2, 1
+    point.origin = tuple(o + np.array([0.5, 0.3, 0.1]))
+    point.color = (0.3, 0.3, 0.4)
+    w.push_light(point)
+    cam = Camera()
+    eye = o + 0.4 * a + 0.3 * b + 0.2 * dn
+    t = c - eye
+    cam.center = tuple(eye)
+    cam.toward = tuple(t / np.linalg.norm(t))
+    cam.up = tuple(b)
+    cam.near = -0.1
+    cam.fovy = float(np.float32(2 * np.arctan(2e-3 / np.linalg.norm(t))))
+    return w, cam

@@ -102,13 +102,13 @@ def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs, pipe
     world, camera, scene = ctx
     frame = rt.Frame.full(96, 72, 5)
     accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
-    os.environ["RT_AMD_DIST_WS_MB"] = cap_mb
-    os.environ["RT_AMD_DIST_PIPELINE"] = pipeline
+    rt.set_option("RT_AMD_DIST_WS_MB", cap_mb)
+    rt.set_option("RT_AMD_DIST_PIPELINE", pipeline)
     try:
         rng, s, v, casts = _run_gpu(scene, camera, frame, epochs, accum=accum)
     finally:
-        del os.environ["RT_AMD_DIST_WS_MB"]
-        del os.environ["RT_AMD_DIST_PIPELINE"]
+        rt.set_option("RT_AMD_DIST_WS_MB", None)
+        rt.set_option("RT_AMD_DIST_PIPELINE", None)
     st = _oracle.rng_init(frame)
     ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, epochs)
     assert np.array_equal(v, wv) and np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and casts == wcasts
@@ -127,7 +127,7 @@ def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
     generates it in the render kernel.  Every mix of the two must leave the reference's stream and the reference's record."""
     world, camera, scene = ctx
     frame = rt.Frame.full(24, 17, 8)
-    os.environ["RT_AMD_RNG_LOOKAHEAD"] = lookahead
+    rt.set_option("RT_AMD_RNG_LOOKAHEAD", lookahead)
     try:
         rng, got, flags, casts = None, [], [], 0
         for n in calls:
@@ -136,7 +136,7 @@ def test_long_streams_cross_many_isaac_blocks(ctx, lookahead, calls):
             flags.append(v)
             casts += c
     finally:
-        del os.environ["RT_AMD_RNG_LOOKAHEAD"]
+        rt.set_option("RT_AMD_RNG_LOOKAHEAD", None)
     st = _oracle.rng_init(frame)
     ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, sum(calls))
     assert np.array_equal(np.concatenate(got).view(np.uint32), ws.view(np.uint32))
@@ -272,11 +272,11 @@ def test_full_size_frame_of_the_headline_configuration(ctx, organisation):
     assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(v, wv) and casts == wcasts
     assert np.array_equal(rng.download(), st)
     if organisation:
-        os.environ["RT_AMD_DIST_WS_MB"] = "2048"
+        rt.set_option("RT_AMD_DIST_WS_MB", "2048")
         try:
             rng2, s2, v2, casts2 = _run_gpu(scene, camera, frame, 2)
         finally:
-            del os.environ["RT_AMD_DIST_WS_MB"]
+            rt.set_option("RT_AMD_DIST_WS_MB", None)
         assert np.array_equal(s2.view(np.uint32), s.view(np.uint32)) and np.array_equal(v2, v) and casts2 == casts
         assert np.array_equal(rng2.download(), st)
 
@@ -311,6 +311,77 @@ def test_scatter_job_of_configs4_equals_the_oracle(ctx):
     assert np.array_equal(accum.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_configs3_job_as_stated_equals_the_oracle(ctx, organisation):
+    """BASELINE.json configs[3] exactly as bench.py times it (`stochastic_pass`): 64 depth-of-field samples per pixel of the
+    1920 x 1080 depth-8 frame from freshly seeded streams in ONE rt_render_distributed call of the default organisation — at this
+    size eight batches of eight epochs pipelined over two workspaces (batch k's shade and unwind kernels beside batch k+1's chain
+    kernel, the look-ahead on its own stream).  Checked against the oracle: the accumulator (the epoch-ordered, filtered sum of
+    main.rs:1157-1167), EVERY generator record after the 64 epochs (516 words per pixel), and the cast count.  The oracle runs the
+    same loop eight epochs at a time (its samples are folded into the expected sum and dropped)."""
+    if not organisation:
+        pytest.skip("configs[3] is stated for the default (split) organisation")
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame.full(1920, 1080, 8)
+    epochs = 64
+    rng = rt.Rng(frame)
+    accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, camera, frame, rng, epochs, accum=accum, ray_count=count)  # asynchronous: the oracle runs beside it
+    st = _oracle.rng_init(frame)
+    want = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+    wcasts = 0
+    desc = world.desc()
+    for _ in range(epochs // 8):
+        ws, wv, c = _oracle.render_distributed(desc, camera, frame, st, 8)
+        wcasts += c
+        for e in range(8):  # the filter, then img += photon, epoch by epoch
+            want += np.where(wv[e][..., None] != 0, ws[e], np.float32(0))
+        del ws, wv
+    torch.cuda.synchronize()
+    assert int(count.item()) == wcasts
+    got = accum.cpu().numpy()
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), f"{bad.sum()} accumulator channels differ, first at {np.argwhere(bad)[:3].tolist()}"
+    assert np.array_equal(rng.download(), st)
+
+
+_EIGHTH = {}
+
+
+@pytest.mark.parametrize("value", [0, 1])
+@pytest.mark.parametrize("switch", ["RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST"])
+def test_a_real_eighth_share_with_each_small_share_switch_forced(ctx, organisation, switch, value):
+    """What a rank of an 8-GPU job renders: rows 3, 11, 19, ... of the 1920 x 1080 depth-8 frame (259 200 pixels — the size the
+    small-share organisation exists for: the chain kernel's pixels grouped by cost, a wave's first chunk its own, the look-ahead
+    ahead of the shade kernel; include/rt_amd.h rt_set_option).  24 epochs, so that the grouping by cost has two batches of history
+    behind it; each switch forced off and on.  Samples, flags, generator records, casts and the accumulator against the oracle."""
+    if not organisation:
+        pytest.skip("the switches belong to the split organisation")
+    import torch
+
+    world, camera, scene = ctx
+    frame = rt.Frame.rows_of_rank(1920, 1080, 8, 3, 8)
+    epochs = 24
+    assert frame.rows * frame.cols == 259_200
+    if not _EIGHTH:
+        st = _oracle.rng_init(frame)
+        ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, epochs)
+        want = np.zeros((frame.rows, frame.cols, 3), dtype=np.float32)
+        for e in range(epochs):
+            want += np.where(wv[e][..., None] != 0, ws[e], np.float32(0))
+        _EIGHTH.update(st=st, ws=ws, wv=wv, wcasts=wcasts, want=want)
+    accum = torch.zeros((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    with rt.options(**{switch: value}):
+        rng, s, v, casts = _run_gpu(scene, camera, frame, epochs, accum=accum)
+    o = _EIGHTH
+    assert np.array_equal(v, o["wv"]) and casts == o["wcasts"]
+    assert ((s.view(np.uint32) == o["ws"].view(np.uint32)) | (np.isnan(s) & np.isnan(o["ws"]))).all()
+    assert np.array_equal(accum.cpu().numpy().view(np.uint32), o["want"].view(np.uint32))
+    assert np.array_equal(rng.download(), o["st"])
+
+
 @pytest.mark.parametrize("refuse", ["1", "3", "99"])
 def test_workspace_that_cannot_be_allocated_means_smaller_batches_then_one_kernel(ctx, organisation, refuse):
     """No device memory for the batch the cap allows: the batch is halved until it fits; not even one epoch fits: the
@@ -320,11 +391,11 @@ def test_workspace_that_cannot_be_allocated_means_smaller_batches_then_one_kerne
     world, camera, _ = ctx
     scene = rt.Scene(world)  # a scene of its own: the workspace is kept per scene and stream, this one must be new
     frame = rt.Frame.full(50, 38, 6)
-    os.environ["RT_AMD_DIAG_WS_REFUSE"] = refuse
+    rt.set_option("RT_AMD_DIAG_WS_REFUSE", refuse)
     try:
         rng, s, v, casts = _run_gpu(scene, camera, frame, 7)
     finally:
-        del os.environ["RT_AMD_DIAG_WS_REFUSE"]
+        rt.set_option("RT_AMD_DIAG_WS_REFUSE", None)
     st = _oracle.rng_init(frame)
     ws, wv, wcasts = _oracle.render_distributed(world.desc(), camera, frame, st, 7)
     assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(v, wv) and casts == wcasts
@@ -398,7 +469,7 @@ def test_two_host_threads_run_pipelined_calls_on_their_own_streams(ctx):
     world, camera, scene = ctx
     frames = [rt.Frame.full(96, 72, 5), rt.Frame.full(80, 60, 6)]
     calls = (4, 3)
-    os.environ["RT_AMD_DIST_WS_MB"] = "16"  # two epochs per batch at these sizes
+    rt.set_option("RT_AMD_DIST_WS_MB", 16)  # two epochs per batch at these sizes
     try:
         def run(frame, stream=None):
             rng = rt.Rng(frame)
@@ -432,7 +503,7 @@ def test_two_host_threads_run_pipelined_calls_on_their_own_streams(ctx):
         for t in threads:
             t.join()
     finally:
-        del os.environ["RT_AMD_DIST_WS_MB"]
+        rt.set_option("RT_AMD_DIST_WS_MB", None)
     assert not errors, errors
     for k in range(2):
         assert np.array_equal(got[k][0].view(np.uint32), want[k][0].view(np.uint32)) and got[k][1] == want[k][1]

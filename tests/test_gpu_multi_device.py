@@ -74,14 +74,13 @@ def test_stochastic_loop_over_a_device_list_is_the_reference_loop():
 
 @pytest.mark.parametrize("stage", [False, True])
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
-def test_device_resident_frame_over_a_device_list(devices, stage, monkeypatch):
+def test_device_resident_frame_over_a_device_list(devices, stage):
     """rt_multi_render_whitted / rt_multi_render_distributed: the frame is assembled in device memory (no host bounce), so that
     rt_post_process_device can follow on the same stream — main()'s whole loop without the image leaving the GPUs.  `stage`
     forces every band through the staging buffer + hipMemcpyPeerAsync route that a second physical device would take."""
     import torch
 
-    if stage:
-        monkeypatch.setenv("RT_AMD_MULTI_FORCE_STAGE", "1")
+    rt.set_option("RT_AMD_MULTI_FORCE_STAGE", 1 if stage else None)
     lib = _capi.amd_lib()
     world, cam = rt.reference_world(), rt.reference_camera()
     desc = world.desc()
@@ -114,6 +113,7 @@ def test_device_resident_frame_over_a_device_list(devices, stage, monkeypatch):
         assert torch.cuda.current_device() == 0
     finally:
         lib.rt_multi_destroy(m)
+        rt.set_option("RT_AMD_MULTI_FORCE_STAGE", None)
 
 
 def test_argument_validation():

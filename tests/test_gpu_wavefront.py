@@ -244,11 +244,11 @@ def test_no_memory_for_the_arenas_means_the_per_pixel_kernel(ref):
     import os
 
     world, cam, _ = ref
-    os.environ["RT_AMD_DIAG_WS_REFUSE"] = "1"
+    rt.set_option("RT_AMD_DIAG_WS_REFUSE", "1")
     try:
         _check(world, cam, rt.Frame.full(200, 150, 6), scene=rt.Scene(world))
     finally:
-        del os.environ["RT_AMD_DIAG_WS_REFUSE"]
+        rt.set_option("RT_AMD_DIAG_WS_REFUSE", None)
 
 
 def _mismatches(got, want):

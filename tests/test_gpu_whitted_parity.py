@@ -96,3 +96,42 @@ def test_device_output_and_ray_counter(ctx):
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert torch.equal(out, out2)
     assert int(cnt.item()) == 2 * want_casts  # the counter accumulates
+
+
+@pytest.mark.parametrize("axis,scale", [((1.0, 2.0, 3.0), 0.37), ((2.0, 1.0, -1.0), 2.5), ((0.3, -1.0, 0.2), 1.0)])
+def test_points_behind_a_spot_light_on_its_axis(axis, scale):
+    """lights.rs:57-60 for a point behind the light, on its axis: the angle's cosine rounds to just below -1 for some pixels, acos is
+    NaN, `NaN > spread` is false — the light asks and its colour is NaN.  The shortcut that answers "outside the cone" from the
+    cosine alone (rt_shade.h light_asks) must leave those to the reference's expression.  Whitted pass (both kernels) and
+    the depth-of-field pass's shade kernel; NaN pixels must sit where the oracle's do, everything else bit for bit."""
+    import torch
+
+    import _scenes
+    from homework_18_graphics_raytracer_amd import _capi
+
+    world, cam = _scenes.behind_spot_world(axis, scale)
+    scene = rt.Scene(world)
+    frame = rt.Frame.full(96, 96, 3)
+    want, want_casts = _oracle.render_whitted(world.desc(), cam, frame)
+    assert np.isnan(want).any(), "the configuration no longer reaches the case it was built for"
+    for variant in (18, 2):
+        _capi.check(_capi.amd_lib().rt_set_variant(variant))
+        try:
+            got, casts = rt.render_whitted_numpy(scene, cam, frame)
+        finally:
+            _capi.check(_capi.amd_lib().rt_set_variant(_capi.DEFAULT_VARIANT))
+        assert casts == want_casts
+        assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+    tile = rt.Frame.full(96, 96, 3)
+    rng = rt.Rng(tile)
+    samples = torch.empty((2, 96, 96, 3), dtype=torch.float32, device="cuda")
+    valid = torch.empty((2, 96, 96), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_distributed(scene, cam, tile, rng, 2, blur=0.0, samples=samples, valid=valid, ray_count=cnt)
+    torch.cuda.synchronize()
+    st = _oracle.rng_init(tile)
+    ws, wv, wc = _oracle.render_distributed(world.desc(), cam, tile, st, 2, blur=0.0)
+    s = samples.cpu().numpy()
+    assert np.isnan(ws).any()
+    assert ((s.view(np.uint32) == ws.view(np.uint32)) | (np.isnan(s) & np.isnan(ws))).all()
+    assert np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wc and np.array_equal(rng.download(), st)

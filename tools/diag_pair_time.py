@@ -60,6 +60,8 @@ if hasattr(lib, "rt_diag_read_shade_time"):
     sb = (C.c_ulonglong * 8)()
     assert lib.rt_diag_read_shade_time(sb, 1) == 0
     st = max(sb[5], 1)
-    nm = ["list building + sort", "request load + material", "lights -> directional, facing", "the cast", "diffuse / specular", None, None]
+    # the per-request kernel: list building + sort | request load + material | lights -> directional, facing | the cast | diffuse / specular
+    # the lights-as-phases kernel (default): place | prepare (request, adjust_normal, light_asks) | a chunk's set-up | the cast | lit bit + finish (colours, lights in order)
+    nm = ["lists (place | build + sort)", "prepare (request load + material)", "chunk set-up (lights -> directional)", "the cast", "after the cast (lit, finish | diffuse / specular)", None, None]
     print(f"shade kernel (all calls since the start, burn included): {sb[6]} wave-casts, {sb[3] / max(sb[6], 1):.0f} ticks per wave-cast; wave time: "
           + ", ".join(f"{nm[k]} {100.0 * sb[k] / st:.1f} %" for k in range(5)))

@@ -6,15 +6,21 @@
 bench.py reads these records for `roofline.traffic` / `roofline.hbm` (the counters are collected in separate rocprofv3 passes,
 never inside the timed run).  HBM bytes = FETCH_SIZE x 2 (gfx950 tallies a 128-byte read request as 64) + WRITE_SIZE, both in
 KB in the summaries (MI355X_MICROARCH.md).  The depth-of-field summaries hold one line per counter and kernel with the number of
-dispatches, their mean and their minimum: tools/bench_distributed.py makes one untimed 1-epoch call before the call that is
-measured, and that call's chain / shade / unwind dispatches (the minimum of each) are taken out of the sums."""
+dispatches, their mean and their minimum.  Round 4 on: the passes are collected with `--warm 1 --fresh 1 --calls 1`, i.e.
+the profiled process makes bench.py's two calls — the untimed one on a generator of its own, then the measured one from fresh
+streams — so HALF of every sum belongs to the measured call (the two calls are the same job; `halve=True`).  Records made from
+older summaries (a 1-epoch warm-up call whose chain / shade / unwind dispatches — the minimum of each — are taken out) keep that rule."""
 import json
 import re
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from homework_18_graphics_raytracer_amd import _capi  # noqa: E402  (the hash of the library's sources; no GPU needed)
+
 P = ROOT / "profiles"
+SOURCES = _capi.sources_sha256()  # run this on the tree the counters were collected with
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 LINE = re.compile(r"^(\w+)\s+n=\s*(\d+)\s+mean=(\S+)\s+min=(\S+)\s+max=(\S+)")
 
@@ -37,7 +43,7 @@ def whitted():
     rec = json.loads(path.read_text()) if path.exists() else {}
     mean = lambda k: c[k][1]
     rec.update({
-        "width": 1920, "height": 1080, "depth": 8, "variant": 18,
+        "width": 1920, "height": 1080, "depth": 8, "variant": 18, "sources_sha256": SOURCES,
         "source": f"profiles/{tag}_pwf_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / TCC_*, separate passes, rt::pwf_kernel, mean per launch; tools/make_traffic.py)",
         "fetch_size_kb": mean("FETCH_SIZE"), "write_size_kb": mean("WRITE_SIZE"),
         "hbm_bytes_per_launch": int(mean("FETCH_SIZE") * 2 * 1024 + mean("WRITE_SIZE") * 1024),
@@ -52,6 +58,7 @@ def whitted():
 
 def dof(pmc_name, out_name, epochs):
     sec = sections(P / pmc_name)
+    halve = "--warm 1 --fresh 1" in (P / pmc_name).read_text().splitlines()[0]
     per, fetch, write, valu, hit, miss = {}, 0.0, 0.0, 0.0, 0.0, 0.0
     for k, c in sec.items():
         warm = k in ("dist_chain", "dist_shade", "dist_unwind")  # one dispatch of each belongs to the untimed 1-epoch call: the minimum
@@ -60,6 +67,8 @@ def dof(pmc_name, out_name, epochs):
             if name not in c:
                 return 0.0
             n, mean, mn = c[name]
+            if halve:
+                return n * mean / 2.0
             return n * mean - (mn if warm and n > 1 else 0.0)
         per[k] = {"fetch": round(total("FETCH_SIZE")), "write": round(total("WRITE_SIZE"))}
         fetch += total("FETCH_SIZE")
@@ -69,7 +78,7 @@ def dof(pmc_name, out_name, epochs):
         miss += total("TCC_MISS_sum")
     samples = 1920 * 1080 * epochs
     rec = {
-        "width": 1920, "height": 1080, "depth": 8, "epochs": epochs,
+        "width": 1920, "height": 1080, "depth": 8, "epochs": epochs, "sources_sha256": SOURCES,
         "source": f"profiles/{pmc_name} (rocprofv3 --pmc, separate passes, tools/bench_distributed.py --epochs {epochs} --calls 1: sums over the dispatches of dist_chain / "
                   "dist_shade / dist_unwind / rng_prepare / rng_scan of the measured call — the untimed 1-epoch call's chain / shade / unwind dispatches taken out; tools/make_traffic.py)",
         "fetch_size_kb": fetch, "write_size_kb": write,

@@ -12,18 +12,18 @@ cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc/$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stochastic --no-pipelined > $O/${TAG}_pmc.$tag.log 2>&1
-  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_dist/$tag -- python3 $R/tools/bench_distributed.py --epochs 64 --calls 1 > $O/${TAG}_pmc_dist.$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_dist/$tag -- python3 $R/tools/bench_distributed.py --epochs 64 --calls 1 --warm 1 --fresh 1 > $O/${TAG}_pmc_dist.$tag.log 2>&1
 done
 cd $R
 { echo "# rocprofv3 --pmc (separate passes), bench.py --steps 5 --warmup 1, 1920x1080 depth 8: mean over the dispatches of rt::pwf_kernel; FETCH_SIZE / WRITE_SIZE in KB"; python3 tools/pmc_summary.py $O/${TAG}_pmc --kernel pwf_kernel; } > $O/${TAG}_pwf_pmc.txt
-{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 64 --calls 1 (configs[3]: 64 epochs from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB"
+{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 64 --calls 1 --warm 1 --fresh 1 (configs[3] twice: bench.py's untimed call on a generator of its own, then the measured one from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; FETCH_SIZE / WRITE_SIZE in KB"
   for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_dist --kernel $k; done; } > $O/${TAG}_dist_pmc.txt
 cd /tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_scatter/$grp -- python3 $R/tools/bench_distributed.py --epochs 5 --calls 1 > $O/${TAG}_pmc_scatter.$grp.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_scatter/$grp -- python3 $R/tools/bench_distributed.py --epochs 5 --calls 1 --warm 1 --fresh 1 > $O/${TAG}_pmc_scatter.$grp.log 2>&1
 done
 cd $R
-{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 5 --calls 1 (configs[4]: 5 epochs from fresh seeds, 1920x1080 depth 8), per kernel: mean per dispatch; KB"
+{ echo "# rocprofv3 --pmc (separate passes), tools/bench_distributed.py --epochs 5 --calls 1 --warm 1 --fresh 1 (configs[4] twice, as above, 1920x1080 depth 8), per kernel: mean per dispatch; KB"
   for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_scatter --kernel $k; done; } > $O/${TAG}_scatter_pmc.txt
 rm -rf $O/${TAG}_pmc_scatter $O/${TAG}_pmc_scatter.*.log
 if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_need.so ]; then python3 tools/diag_need.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lane_tests_needed.txt; fi

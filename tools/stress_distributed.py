@@ -69,16 +69,16 @@ for k in range(a.configs):
     split = int(rng.integers(0, 2))
     cap = str(int(rng.choice([1, 2, 8, 64, 16384])))
     lib.rt_set_distributed_split(split)
-    os.environ["RT_AMD_DIST_WS_MB"] = cap
+    rt.set_option("RT_AMD_DIST_WS_MB", cap)
     scene = rt.Scene(world)
     s, v, casts, st = run_gpu(scene, cam, frame, calls)
     want_st = _oracle.rng_init(frame)
     ws, wv, wcasts = _oracle.render_distributed(world.desc(), cam, frame, want_st, total)
     ok = same(s, ws) and np.array_equal(v, wv) and casts == wcasts and np.array_equal(st, want_st)
     if ok and k % 5 == 0:
-        os.environ["RT_AMD_RNG_LOOKAHEAD"] = "0"
+        rt.set_option("RT_AMD_RNG_LOOKAHEAD", "0")
         s2, v2, casts2, st2 = run_gpu(scene, cam, frame, [total])
-        del os.environ["RT_AMD_RNG_LOOKAHEAD"]
+        rt.set_option("RT_AMD_RNG_LOOKAHEAD", None)
         ok = same(s2, s) and np.array_equal(v2, v) and casts2 == casts and np.array_equal(st2, st)
     if not ok:
         bad += 1
@@ -86,6 +86,6 @@ for k in range(a.configs):
     if k % 10 == 0:
         print(f"... {k + 1} configurations, {bad} bad", flush=True)
 lib.rt_set_distributed_split(-1)
-os.environ.pop("RT_AMD_DIST_WS_MB", None)
+rt.set_option("RT_AMD_DIST_WS_MB", None)
 print(f"{a.configs} configurations: {bad} bad")
 sys.exit(1 if bad else 0)
