@@ -349,7 +349,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
         rt_scene *mut = const_cast<rt_scene *>(scene); /* workspaces are the only mutable part of a scene */
         std::lock_guard<std::mutex> lock(mut->ws_mutex);
         Workspace &ws = mut->workspaces[stream];
-        if (!ws.d_counters) RT_HIP(hipMalloc(reinterpret_cast<void **>(&ws.d_counters), 256));
+        RT_HIP(ensure_counters(ws));
         if (variant & RT_VARIANT_PWF) {
             /* The kernel keeps one LDS word per 64 ring slots and per 64 nodes, so an arena holds 64 K ring slots at most.
              * A tile too large for that at the budget asked for (beyond ~8 Mpixel at 6 nodes per pixel) is rendered as

@@ -32,6 +32,7 @@ ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen per size)")
 ap.add_argument("--no-parity", action="store_true")
 ap.add_argument("--out", default=None)
+ap.add_argument("--tile-order", default="default", choices=["default", "image"], help="image: the wavefront kernel takes its 8x8 tiles in image order (rt_diag_set_tile_order) instead of scattered by the golden-section stride: all workgroups then work in one region of the image at a time")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
@@ -84,6 +85,12 @@ with tempfile.TemporaryDirectory() as tmp:
         else:
             W, H = 480, 270
         frame = rt.Frame.full(W, H, a.depth)
+        d_order = None
+        if a.tile_order == "image":
+            import ctypes as C
+            lib.rt_diag_set_tile_order.argtypes = [C.c_void_p]
+            d_order = torch.arange((W * H + 63) // 64, dtype=torch.int32, device="cuda")
+            lib.rt_diag_set_tile_order(C.c_void_p(d_order.data_ptr()))
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
         cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
         for v in a.variants:
@@ -110,10 +117,12 @@ with tempfile.TemporaryDirectory() as tmp:
                    "scene_bytes_device": T * (128 + 64), "scene_file_bytes": path.stat().st_size,
                    "width": W, "height": H, "depth": a.depth, "frames": n, "ms_per_frame": round(ms, 4), "casts_per_frame": casts,
                    "Mrays_per_s": round(casts / ms / 1e3, 2), "Gtri_tests_per_s": round(casts * T / ms / 1e6, 2),
-                   "parity_vs_oracle_small_frame": parity}
+                   "parity_vs_oracle_small_frame": parity, "tile_order": a.tile_order}
             lines.append(rec)
             print(json.dumps(rec), flush=True)
         _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
+        if d_order is not None:
+            lib.rt_diag_set_tile_order(None)
         del scene
 if a.out:
     with open(a.out, "w") as f:
