@@ -203,7 +203,7 @@ def stochastic_pass(scene, camera, width, height, depth, rank, world_size, distr
         flop_per_cast = world_desc.n_triangles * FLOP_PER_TRIANGLE_TEST + world_desc.n_spheres * FLOP_PER_SPHERE_TEST
     tflops = casts_rank * flop_per_cast / (render_ms * 1e-3) / 1e12
     # the pass's kernels from this run's own HIP events (rank 0's): each one's summed duration under the overlap of a pipelined call
-    names = ("rng look-ahead (rng_scan + rng_prepare)", "dist_chain_kernel", "dist_shade_lights_kernel", "dist_unwind_kernel")
+    names = ("rng look-ahead (rng_scan + rng_prepare)", "dist_chain_kernel", "dist_shade_kernel", "dist_unwind_kernel")
     k_total = sum(k_ms) or 1.0
     kernels = {names[i]: {"ms_sum": round(k_ms[i], 3), "launches": int(k_n[i]), "share_of_kernel_time": round(k_ms[i] / k_total, 3)} for i in range(4)}
     kernel_note = ("the pass's kernels together; live HIP events of this run, summed per kernel (they overlap in a pipelined call, so the sums exceed render_ms): "

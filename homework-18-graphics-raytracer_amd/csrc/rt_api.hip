@@ -24,7 +24,7 @@ extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = stati
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
     "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
     "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
-    "RT_AMD_SHADE_KERNEL", "RT_AMD_SHADE_CAP", "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT"};
+    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT"};
 static std::atomic<int> g_opt_set[rt::OPT_COUNT];
 static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
 static std::once_flag g_opt_once;

@@ -248,14 +248,9 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         dp.own_first_chunk = rt::option(rt::OPT_DIST_OWN_FIRST, small_share ? 1 : 0) != 0 ? 1u : 0u; /* rt_kernels.h */
         const bool prep_first = rt::option(rt::OPT_DIST_PREP_FIRST, 1) != 0; /* 0: shade kernel and look-ahead start together */
         const size_t cap = (size_t)std::max<long long>(0, rt::option(rt::OPT_DIST_WS_MB, pipeline ? 32768 : 16384)) << 20;
-        /* the shade stage's bins (rt_kernels.h DistParams::bin_*): one array of items per call, behind the workspace(s) — the shade
-         * kernels of successive batches follow each other on one stream */
-        const bool bins = scene->ks.n_lights >= 1u && scene->ks.n_lights <= 8u;
-        auto bin_bytes = [&](uint32_t epochs) { return bins ? (rt::dist_bin_items(n_pixels * epochs) * DIST_BIN_ITEM_BYTES + 255u) & ~(size_t)255u : (size_t)0; };
-        const size_t per_epoch_bins = bins ? 7u * DIST_BIN_ITEM_BYTES * n_pixels : 0u;
-        uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / (per_epoch + per_epoch_bins)));
+        uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
         if (pipeline && batch < n_epochs) /* more than one batch: each workspace gets half the cap */
-            batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / (2u * per_epoch + per_epoch_bins)));
+            batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / 2u / per_epoch));
         if (batch < n_epochs) batch = (n_epochs + (n_epochs + batch - 1u) / batch - 1u) / ((n_epochs + batch - 1u) / batch); /* as many batches, of equal size */
         uint32_t n_buf = pipeline && batch < n_epochs ? 2u : 1u;
         size_t o_hdr = 0, o_req = 0, o_shade = 0, o_frame = 0;
@@ -269,7 +264,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             o_frame = carve(off, n_samples * (slots - 1u) * sizeof(float4));
             return off;
         };
-        auto total_bytes = [&](uint32_t epochs, uint32_t bufs) { return layout(epochs) * bufs + bin_bytes(epochs); };
+        auto total_bytes = [&](uint32_t epochs, uint32_t bufs) { return layout(epochs) * bufs; };
         char *base = nullptr;
         size_t buf_stride = 0;
         {
@@ -308,12 +303,6 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             dp.work_queue = ws.d_counters;
             base = static_cast<char *>(ws.d_split);
             buf_stride = layout(batch); /* sets the offsets for the batch size settled on */
-            if (bins && base != nullptr) {
-                dp.bin_ctrl = ws.d_counters + RT_WS_BIN_CTRL;
-                dp.bin_capacity = (uint32_t)std::min<size_t>(rt::dist_bin_items(n_pixels * batch), 0xffffffc0u);
-                dp.bin_ray = reinterpret_cast<uint4 *>(base + buf_stride * n_buf);
-                dp.bin_at = reinterpret_cast<uint32_t *>(base + buf_stride * n_buf + (size_t)dp.bin_capacity * sizeof(uint4));
-            }
         }
         if (base == nullptr) goto one_kernel;
         if (batch >= n_epochs) n_buf = 1u;
@@ -362,7 +351,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                  * kernel starts after it instead of taking that LDS first (between two chain kernels of a 1/8 share of the 1080p
                  * frame 1.1 -> 0.3 ms: 0.38 -> 0.365 ms per epoch, a 1/4 share 0.553 -> 0.517, the whole frame 1.685 -> 1.669) */
                 if (e == hipSuccess && prep_first && rng->ahead) e = hipStreamWaitEvent(rng->tail, rng->ev_prepared, 0);
-                if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, dist_waves, rng->tail, tail_ev);
+                if (e == hipSuccess) e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, rng->tail, tail_ev);
                 if (e == hipSuccess && by_cost) {
                     e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, rng->tail);
                     rng->order_valid[b] = e == hipSuccess;
@@ -370,7 +359,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                 if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], rng->tail); /* ... then: and the unwind has read it */
                 tail_used[b] = e == hipSuccess;
             } else if (e == hipSuccess) {
-                e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, dist_waves, stream, tail_ev);
+                e = rt::launch_dist_shade_unwind(scene->ks, kf, dp, stream, tail_ev);
                 if (e == hipSuccess && by_cost) {
                     e = rt::launch_dist_pixel_order(pix_cost, pix_order, (uint32_t)n_pixels, pix_scratch, stream);
                     rng->order_valid[b] = e == hipSuccess;

@@ -38,10 +38,9 @@
 
 /* Per-(scene, stream) scratch.  Launches on one stream are ordered, so they can share it; other streams get
  * their own.  Grow-only; allocated on the first call that needs it (not inside a graph capture). */
-#define RT_WS_COUNTER_BYTES (256u + DIST_BIN_CTRL_WORDS * 4u)
-#define RT_WS_BIN_CTRL 64u /* word offset of the shade stage's bin control block (DIST_BIN_CTRL_WORDS words; rt_kernels.h) */
+#define RT_WS_COUNTER_BYTES 256u
 struct Workspace {
-    uint32_t *d_counters = nullptr; /* RT_WS_COUNTER_BYTES, zeroed once: [0] the stochastic pass's chunk counter, [RT_WS_BIN_CTRL ..] the bins' control block */
+    uint32_t *d_counters = nullptr; /* RT_WS_COUNTER_BYTES, zeroed once: [0] the stochastic pass's chunk counter */
     void *d_pwf = nullptr; /* persistent-wavefront path: two blocks of global words, the frame description, one arena per workgroup */
     size_t pwf_bytes = 0;
     /* Launches on this workspace alternate between the two blocks of global words: a launch's last workgroup zeroes the

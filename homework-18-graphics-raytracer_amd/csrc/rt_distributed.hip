@@ -1182,18 +1182,26 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
         for (uint32_t light_i = 0; light_i < sc.n_lights; ++light_i) { /* wave-uniform */
 #endif
             const auto &L = uniform_ref(sc.lights + light_i);
-            DirLight dl;
-            dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
+            /* does the light ask for a shadow cast (main.rs:413-433)?  light_asks answers without a spot light's acos wherever the
+             * angle is clear of the cone's edge (rt_shade.h); the light's colour — a spot light's powf — waits for the lit lanes */
+            V3 l_direction = v3(0.0f, 0.0f, 0.0f);
+#ifdef RT_SHADE_NO_LIGHT_ASKS /* A/B (round 3): the light evaluated in full for every active lane */
+            DirLight dl0;
+            dl0.direction = dl0.color = v3(0.0f, 0.0f, 0.0f);
             bool need = false;
-            if (active && approximate_into_directional(L, pos, &dl)) {
-                const float cosine = -dot(dl.direction, adj_n);
+            if (active && approximate_into_directional(L, pos, &dl0)) {
+                const float cosine = -dot(dl0.direction, adj_n);
                 need = !(cosine <= 0.0f);
             }
+            l_direction = dl0.direction;
+#else
+            const bool need = light_asks(L, uniform_ref(sc.light_aux + light_i), pos, adj_n, &l_direction) && active;
+#endif
             RT_SHADE_TICK(2)
             if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
             Ray req;
             req.o = pos;
-            req.d = -dl.direction;
+            req.d = -l_direction;
             req.mode = FACE_BACK;
             req.excl = pack_excl(prim, FACE_BACK);
 #ifdef RT_DIST_SHADE_NO_PAIRS /* A/B */
@@ -1228,6 +1236,9 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
                     }
                 }
                 if (lit) {
+                    DirLight dl;
+                    dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
+                    (void)approximate_into_directional(L, pos, &dl); /* the light asked: Some */
                     const V3 light_direction = req.d;
                     const V3 diffuse = get_diffuse(m, adj_n, light_direction) * dl.color;
                     const V3 specular = get_specular(m, adj_n, -view, light_direction) * dl.color;
@@ -1242,407 +1253,6 @@ __global__ __launch_bounds__(RT_DIST_SHADE_THREADS, RT_DIST_SHADE_MIN_WAVES) voi
     sdt[5] = __builtin_readcyclecounter() - stick0;
     if (lane == 0u) for (int q = 0; q < 7; ++q) atomicAdd(&g_shade_time[q], sdt[q]);
 #endif
-    if (dp.ray_count != nullptr) {
-        for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
-        if (lane == 0u && casts != 0u) atomicAdd(dp.ray_count, (unsigned long long)casts);
-    }
-}
-
-/* ---- get_shade with the shadow rays BINNED over the whole batch (round 4; the default for scenes of up to DIST_BIN_MAX_LIGHTS lights) ----
- * Three quarters of dist_shade_kernel's VALU instructions are its casts (profiles/r04a_shade_attribution.txt), and what a cast costs
- * a wave is decided by the lanes it is run with: it runs for a light as soon as ONE lane faces it (49 of 64 lanes at work), and it
- * runs a clustered node for all lanes as soon as one lane's line meets its bounding sphere — 41.6 of the reference scene's 64
- * triangles per wave-cast where a lane's own ray needs 15.9 (profiles/r03_lane_tests_needed.txt).  Ordering the requests of a
- * 256-sample tile better is not enough (tried twice, profiles/r04_ab1..3: per-light lists in LDS, also ordered by cluster class —
- * fuller and more alike waves, but three rounds of per-request work instead of one, and a tile's lists end in mixed chunks).  So the
- * shadow rays of the WHOLE batch are binned:
- *
- *   dist_bin_plan_kernel    one thread: this batch's bin capacities from the last batch's counts (the bins share one array of items);
- *   dist_bin_prepare_kernel every request once: position, normal, object, primitive -> material normal -> adjust_normal
- *                           (main.rs:410, left in the request's spare words) -> for every light, light_asks (rt_shade.h: main.rs:413-433
- *                           decided once, exactly) -> the shadow ray's CLASS — which of the first two clustered top-level nodes its
- *                           line can meet — -> an item {position, primitive, request} appended to bin (light, class);
- *   dist_bin_cast_kernel    persistent waves take 64 items of ONE bin: every lane casts, for the same light (scalar record), and the
- *                           lanes' rays need the same clusters; a lit lane ORs its light's bit into its request's result word;
- *   dist_bin_finish_kernel  every request once more: view direction and colours (the other half of its 64 bytes), then its lit lights
- *                           IN ORDER (main.rs:458-461: float addition does not associate), their colours (lights.rs:48-93) evaluated
- *                           for lit lanes only, and the sum is written.
- *
- * A bin that is full (the plan is an estimate; the first batch of a call has none) leaves the item with its request: a `pending`
- * bit, and the finish kernel makes that cast itself.  Same operations on the same values as dist_shade_kernel — which stays for
- * scenes with more lights and as the A/B baseline (RT_AMD_SHADE_KERNEL=0) — so samples, flags and cast counts are bit-identical. */
-#define DIST_BIN_MAX_LIGHTS 8u
-#define DIST_BIN_CLASSES 4u
-#define DIST_BIN_MAX (DIST_BIN_MAX_LIGHTS * DIST_BIN_CLASSES)
-/* Every bin is kept as DIST_BIN_SUBS sub-bins, each with its own counter and its own stretch of the item arrays: a wave appends to
- * the sub-bin its number picks.  (One counter per bin was tried first — profiles/r04_ab4_binned_single_counters.txt: five million
- * appends per batch on twelve words, and a chunk counter taken 1.6 million times, are served one after the other, ~11 ns each: the
- * prepare kernel took 28 ms and the cast kernel 40 where their instructions need 1 and 3.)  REGION r = bin * DIST_BIN_SUBS + sub.
- * control block (u32 words): [1] samples of the batch that left the counts behind (0: none), [2] chunks of this batch (index kernel),
- * [DIST_BIN_COUNT + sub * DIST_BIN_MAX + bin] items appended to the region (attempted: may exceed its room),
- * [DIST_BIN_START + r] where region r starts in the item arrays ([.. + regions] = the end),
- * [DIST_BIN_PREFIX + k] chunks before the k-th region in the order the cast kernel takes them, [DIST_BIN_ORDER + k] that region */
-#define DIST_BIN_SUBS 16u
-#define DIST_BIN_REGIONS (DIST_BIN_MAX * DIST_BIN_SUBS)
-#define DIST_BIN_COUNT 16u
-#define DIST_BIN_START (DIST_BIN_COUNT + DIST_BIN_REGIONS)
-#define DIST_BIN_PREFIX (DIST_BIN_START + DIST_BIN_REGIONS + 1u)
-#define DIST_BIN_ORDER (DIST_BIN_PREFIX + DIST_BIN_REGIONS + 1u)
-static_assert(DIST_BIN_ORDER + DIST_BIN_REGIONS <= DIST_BIN_CTRL_WORDS, "the control block (rt_kernels.h)");
-#define DIST_PREP_THREADS 256
-#define DIST_PREP_HDR 8u
-
-/* this batch's regions from the last batch's counts: a bin's share of the item arrays is proportional to what it received (scaled
- * to this batch's samples, an eighth on top; no history: equal shares), cut evenly into its sub-bins */
-__global__ __launch_bounds__(64) void dist_bin_plan_kernel(uint32_t *ctrl, uint32_t n_bins, uint32_t capacity, uint32_t n_samples) {
-    __shared__ unsigned long long want[DIST_BIN_MAX];
-    __shared__ uint32_t share[DIST_BIN_MAX + 1u];
-    const uint32_t t = threadIdx.x;
-    const uint32_t prev_samples = ctrl[1];
-    if (t < n_bins) {
-        unsigned long long got = 0ull;
-        for (uint32_t sub = 0; sub < DIST_BIN_SUBS; ++sub) got += ctrl[DIST_BIN_COUNT + sub * DIST_BIN_MAX + t];
-        want[t] = prev_samples != 0u ? (got * n_samples / prev_samples) * 9ull / 8ull + 4096ull : 1ull;
-    }
-    __syncthreads();
-    if (t == 0u) {
-        unsigned long long total = 0ull;
-        for (uint32_t b = 0; b < n_bins; ++b) total += want[b];
-        uint32_t at = 0u;
-        for (uint32_t b = 0; b < n_bins; ++b) {
-            share[b] = at;
-            at += DIST_BIN_SUBS * (((uint32_t)((unsigned long long)capacity * want[b] / total) / DIST_BIN_SUBS) & ~63u);
-        }
-        share[n_bins] = at;
-        ctrl[1] = n_samples;
-        ctrl[2] = 0u;
-    }
-    __syncthreads();
-    for (uint32_t r = t; r < n_bins * DIST_BIN_SUBS; r += 64u) {
-        const uint32_t b = r / DIST_BIN_SUBS, sub = r % DIST_BIN_SUBS;
-        const uint32_t each = (share[b + 1u] - share[b]) / DIST_BIN_SUBS;
-        ctrl[DIST_BIN_START + r] = share[b] + sub * each;
-        ctrl[DIST_BIN_COUNT + sub * DIST_BIN_MAX + b] = 0u;
-    }
-    if (t == 0u) ctrl[DIST_BIN_START + n_bins * DIST_BIN_SUBS] = share[n_bins];
-}
-
-/* after the prepare kernel: the chunks of every region, in the order the cast kernel takes them — class by class, the dearest class
- * (both clusters) first, so that what is left for the end of the kernel is cheap */
-__global__ __launch_bounds__(64) void dist_bin_index_kernel(uint32_t *ctrl, uint32_t n_lights, unsigned long long *ray_count) {
-    if (threadIdx.x != 0u) return;
-    uint32_t chunks = 0u, k = 0u;
-    unsigned long long items = 0ull; /* = the casts the cast kernel makes: counted here, once, instead of by 1.6 million waves on one word */
-    for (uint32_t c = 0; c < DIST_BIN_CLASSES; ++c) {
-        const uint32_t cls = DIST_BIN_CLASSES - 1u - c;
-        for (uint32_t l = 0; l < n_lights; ++l) {
-            const uint32_t bin = l * DIST_BIN_CLASSES + cls;
-            for (uint32_t sub = 0; sub < DIST_BIN_SUBS; ++sub, ++k) {
-                const uint32_t r = bin * DIST_BIN_SUBS + sub;
-                const uint32_t room = ctrl[DIST_BIN_START + r + 1u] - ctrl[DIST_BIN_START + r];
-                const uint32_t asked = ctrl[DIST_BIN_COUNT + sub * DIST_BIN_MAX + bin];
-                ctrl[DIST_BIN_PREFIX + k] = chunks;
-                ctrl[DIST_BIN_ORDER + k] = r;
-                chunks += ((asked < room ? asked : room) + 63u) >> 6;
-                items += asked < room ? asked : room;
-            }
-        }
-    }
-    ctrl[DIST_BIN_PREFIX + k] = chunks;
-    ctrl[2] = chunks;
-    if (ray_count != nullptr && items != 0ull) atomicAdd(ray_count, items);
-}
-
-__device__ __forceinline__ uint32_t sh2_append(uint32_t *counter, bool want, uint32_t lane) {
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0ull) return 0u;
-    const int leader = (int)__builtin_ctzll(mask);
-    uint32_t base = 0u;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-/* The live (slot, sample) pairs of a workgroup's 256 samples -> `word[]` in LDS (slot << 8 | sample), appended wave by wave and slot
- * by slot, at most `per` of them per round; returns how many this round placed.  hdr: [0] the tile's requests, [1] placed this round. */
-__device__ __forceinline__ uint32_t dist_place_requests(uint32_t *hdr, uint32_t *word, uint32_t cnt, uint32_t *k_done, uint32_t per, uint32_t round, uint32_t tid, uint32_t lane) {
-    if (round != 0u) {
-        __syncthreads(); /* everybody is through with the previous round's words */
-        if (tid == 1u) hdr[1] = 0u;
-        __syncthreads();
-    }
-    bool over = false;
-    for (uint32_t k = *k_done;; ++k) {
-        const bool want = !over && k < cnt;
-        if (__builtin_amdgcn_ballot_w64(want) == 0ull) break;
-        const uint32_t idx = sh2_append(&hdr[1], want, lane);
-        if (want) {
-            if (idx < per) {
-                word[idx] = (k << 8) | tid;
-                *k_done = k + 1u;
-            } else {
-                over = true; /* the counter only grows: whatever this thread appends later in this round is over too */
-            }
-        }
-    }
-    __syncthreads();
-    return hdr[1] < per ? hdr[1] : per;
-}
-/* hdr[0] <- the requests of this workgroup's tile; returns this thread's sample's count (its requests are slots 0 .. cnt - 1) */
-__device__ __forceinline__ uint32_t dist_count_requests(const DistParams &dp, size_t n_samples, size_t tile0, uint32_t *hdr, uint32_t tid, uint32_t lane) {
-    uint32_t cnt = 0u;
-    if (tile0 + tid < n_samples) {
-        const uint32_t h = dp.sp_hdr[tile0 + tid];
-        cnt = (h & 0xffu) + ((h >> 8) & 1u);
-    }
-    if (tid < DIST_PREP_HDR) hdr[tid] = 0u;
-    __syncthreads();
-    uint32_t c = cnt;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if (lane == 0u && c != 0u) atomicAdd(&hdr[0], c);
-    __syncthreads();
-    return cnt;
-}
-
-__global__ __launch_bounds__(DIST_PREP_THREADS) void dist_bin_prepare_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t cap,
-                                                                          uint32_t *ctrl, uint4 *item_ray, uint32_t *item_at) {
-    extern __shared__ uint32_t prep_lds[];
-    uint32_t *const hdr = prep_lds, *const word = prep_lds + DIST_PREP_HDR;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const size_t tile0 = (size_t)blockIdx.x * DIST_PREP_THREADS; /* a sample per thread */
-    const uint32_t nl = sc.n_lights;
-    const uint32_t sub = (blockIdx.x * (DIST_PREP_THREADS / 64u) + (tid >> 6)) % DIST_BIN_SUBS; /* this wave's sub-bins */
-    const uint32_t cnt = dist_count_requests(dp, n_samples, tile0, hdr, tid, lane);
-    const uint32_t total = hdr[0];
-    if (total == 0u) return;
-    const uint32_t rounds = (total + cap - 1u) / cap;
-    const uint32_t per = (total + rounds - 1u) / rounds;
-    uint32_t k_done = 0u;
-    for (uint32_t round = 0; round < rounds; ++round) {
-        const uint32_t n = dist_place_requests(hdr, word, cnt, &k_done, per, round, tid, lane);
-        for (uint32_t e0 = tid & ~63u; e0 < n; e0 += DIST_PREP_THREADS) {
-            const uint32_t e = e0 + lane;
-            const bool active = e < n;
-            V3 pos = v3(0.0f, 0.0f, 0.0f), normal = v3(0.0f, 0.0f, 1.0f);
-            float u = 0.0f;
-            uint32_t obj = 0u, prim = 0u;
-            size_t at = 0;
-            if (active) {
-                const uint32_t w = word[e];
-                at = (size_t)(w >> 8) * n_samples + tile0 + (w & 0xffu);
-                const uint4 *r = dp.sp_req + at * 4u;
-                const uint4 a = r[0], b = r[1];
-                obj = reinterpret_cast<const uint32_t *>(r + 2)[3];
-                prim = reinterpret_cast<const uint32_t *>(r + 3)[0];
-                pos = v3(duf(a.x), duf(a.y), duf(a.z)); u = duf(a.w);
-                normal = v3(duf(b.x), duf(b.y), duf(b.z));
-            }
-            const Mat m = material_approx(sc.materials[obj], u, 0.0f); /* its normal only (a function of u): the rest is not evaluated */
-            const V3 adj_n = adjust_normal(m.normal, normal); /* main.rs:410 */
-            uint32_t pending = 0u;
-            for (uint32_t l = 0; l < nl; ++l) { /* wave-uniform: the light's record through scalar loads */
-                V3 direction;
-                const bool asks = light_asks(uniform_ref(sc.lights + l), uniform_ref(sc.light_aux + l), pos, adj_n, &direction) && active;
-                if (__builtin_amdgcn_ballot_w64(asks) == 0ull) continue;
-                /* the class: bit b = the shadow ray's line meets the b-th clustered top-level node's bounding sphere (a wave runs such a
-                 * node for all its lanes as soon as one lane's does, rt_cast.h).  It only decides which rays are cast together. */
-                uint32_t cls = 0u, nbits = 0u;
-                for (uint32_t k = 0; k < sc.n_segments && nbits < 2u;) {
-                    const NodeRec g = load_node(sc.segments + k);
-                    if (g.h0.z != 0u) {
-                        const V3 disp = v3(__uint_as_float(g.h1.x), __uint_as_float(g.h1.y), __uint_as_float(g.h1.z)) - pos;
-                        const V3 cr = cross(disp, direction);
-                        if (!(dot(cr, cr) > __uint_as_float(g.h0.w) * dot(direction, direction))) cls |= 1u << nbits;
-                        nbits += 1u;
-                    }
-                    k = g.h1.w;
-                }
-                for (uint32_t c = 0; c < DIST_BIN_CLASSES; ++c) { /* wave-uniform */
-                    const bool mine = asks && cls == c;
-                    if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
-                    const uint32_t bin = l * DIST_BIN_CLASSES + c, region = bin * DIST_BIN_SUBS + sub;
-                    const uint32_t idx = sh2_append(ctrl + DIST_BIN_COUNT + sub * DIST_BIN_MAX + bin, mine, lane);
-                    const uint32_t start = ctrl[DIST_BIN_START + region], room = ctrl[DIST_BIN_START + region + 1u] - start;
-                    if (mine) {
-                        if (idx < room) {
-                            item_ray[start + idx] = make_uint4(dfu(pos.x), dfu(pos.y), dfu(pos.z), prim);
-                            item_at[start + idx] = (uint32_t)at;
-                        } else {
-                            pending |= 1u << l; /* the bin is full: the finish kernel makes this cast */
-                        }
-                    }
-                }
-            }
-            if (active) {
-                uint4 *r3 = dp.sp_req + at * 4u + 3u;
-                *r3 = make_uint4(prim, dfu(adj_n.x), dfu(adj_n.y), dfu(adj_n.z)); /* the request's spare words */
-                dp.sp_shade[at] = make_float4(0.0f, 0.0f, 0.0f, duf(pending << 16)); /* .w: lit by (bits 0-7, the cast kernel) | pending (bits 16-23) */
-            }
-        }
-    }
-}
-
-#ifndef RT_DIST_BIN_CAST_WAVES
-#define RT_DIST_BIN_CAST_WAVES 6 /* the intersection loop owns s34..s99: at 8 waves per SIMD the compiler may hand out fewer SGPRs than that */
-#endif
-__global__ __launch_bounds__(64, RT_DIST_BIN_CAST_WAVES) void dist_bin_cast_kernel(const KernelScene sc, const DistParams dp, const uint32_t *ctrl, const uint4 *item_ray, const uint32_t *item_at) {
-    const uint32_t lane = threadIdx.x & 63u;
-    /* ONE chunk per wave (the grid covers the item arrays; a wave beyond the batch's chunks leaves at once): workgroups start in
-     * index order, i.e. the dearest class first, and the hardware hands the next chunk to whichever slot falls free */
-    const uint32_t c = blockIdx.x;
-    if (c < ctrl[2]) {
-        const uint32_t n_regions = sc.n_lights * DIST_BIN_CLASSES * DIST_BIN_SUBS;
-        uint32_t lo = 0u, hi = n_regions; /* the last k with prefix[k] <= c */
-        while (hi - lo > 1u) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_PREFIX + mid]) <= c) lo = mid; else hi = mid;
-        }
-        const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_ORDER + lo]);
-        const uint32_t within = c - (uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_PREFIX + lo]);
-        const uint32_t bin = region / DIST_BIN_SUBS, sub = region % DIST_BIN_SUBS;
-        const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_START + region]);
-        const uint32_t room = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_START + region + 1u]) - start;
-        const uint32_t asked = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctrl[DIST_BIN_COUNT + sub * DIST_BIN_MAX + bin]);
-        const uint32_t first = start + within * 64u;
-        const uint32_t count = (asked < room ? asked : room) - within * 64u;
-        const uint32_t l = bin / DIST_BIN_CLASSES;
-        const bool have = lane < count;
-        uint4 it = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t at = 0u;
-        if (have) {
-            it = item_ray[first + lane];
-            at = item_at[first + lane];
-        }
-        const V3 pos = v3(duf(it.x), duf(it.y), duf(it.z));
-        const auto &L = uniform_ref(sc.lights + l);
-        const V3 l_origin = v3(L.origin[0], L.origin[1], L.origin[2]);
-        V3 direction; /* of the light at the point, as approximate_into_directional has it (lights.rs:52, 69, 81) */
-        if (L.kind == RT_LIGHT_DIRECTIONAL) direction = v3(L.direction[0], L.direction[1], L.direction[2]);
-        else direction = normalize(pos - l_origin);
-        Ray req;
-        req.o = pos;
-        req.d = -direction;
-        req.mode = FACE_BACK;
-        req.excl = pack_excl(it.w, FACE_BACK);
-        CastResult cr;
-        cr.prim = -1;
-        cr.t = 0.0f;
-        cr.bf = 0u;
-        cr.a0 = cr.a1 = cr.a2 = 0.0f;
-        if (have) cr = cast_asm(sc, req);
-        if (have) { /* (the casts are counted by the index kernel: one per item) */
-            bool lit = true; /* main.rs:436-452 */
-            if (cr.prim >= 0) {
-                const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
-                if (has_origin) {
-                    const V3 occ = req.o + req.d * cr.t;
-                    if (distance(pos, occ) < distance(pos, l_origin)) lit = false;
-                } else {
-                    lit = false;
-                }
-            }
-            if (lit) atomicOr(reinterpret_cast<uint32_t *>(dp.sp_shade + at) + 3, 1u << l);
-        }
-    }
-}
-
-__global__ __launch_bounds__(DIST_PREP_THREADS) void dist_bin_finish_kernel(const KernelScene sc, const DistParams dp, const size_t n_samples, const uint32_t cap) {
-    extern __shared__ uint32_t prep_lds[];
-    uint32_t *const hdr = prep_lds, *const word = prep_lds + DIST_PREP_HDR;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const size_t tile0 = (size_t)blockIdx.x * DIST_PREP_THREADS;
-    const uint32_t nl = sc.n_lights;
-    const uint32_t cnt = dist_count_requests(dp, n_samples, tile0, hdr, tid, lane);
-    const uint32_t total = hdr[0];
-    uint32_t casts = 0u;
-    if (total != 0u) {
-        const uint32_t rounds = (total + cap - 1u) / cap;
-        const uint32_t per = (total + rounds - 1u) / rounds;
-        uint32_t k_done = 0u;
-        for (uint32_t round = 0; round < rounds; ++round) {
-            const uint32_t n = dist_place_requests(hdr, word, cnt, &k_done, per, round, tid, lane);
-            for (uint32_t e0 = tid & ~63u; e0 < n; e0 += DIST_PREP_THREADS) {
-                const uint32_t e = e0 + lane;
-                const bool active = e < n;
-                size_t at = 0;
-                uint32_t bits = 0u;
-                if (active) {
-                    const uint32_t w = word[e];
-                    at = (size_t)(w >> 8) * n_samples + tile0 + (w & 0xffu);
-                    bits = dfu(dp.sp_shade[at].w);
-                }
-                uint32_t lit_by = bits & 0xffu;
-                const uint32_t pending = (bits >> 16) & 0xffu;
-                const bool work = (lit_by | pending) != 0u;
-                V3 pos = v3(0.0f, 0.0f, 0.0f), view = v3(0.0f, 0.0f, 1.0f), adj_n = v3(0.0f, 0.0f, 1.0f);
-                float u = 0.0f, v = 0.0f;
-                uint32_t obj = 0u, prim = 0u;
-                if (__builtin_amdgcn_ballot_w64(work) != 0ull) {
-                    if (work) {
-                        const uint4 *r = dp.sp_req + at * 4u;
-                        const uint4 a = r[0], c4 = r[2], d4 = r[3];
-                        v = duf(reinterpret_cast<const uint32_t *>(r + 1)[3]);
-                        pos = v3(duf(a.x), duf(a.y), duf(a.z)); u = duf(a.w);
-                        view = v3(duf(c4.x), duf(c4.y), duf(c4.z)); obj = c4.w;
-                        prim = d4.x; adj_n = v3(duf(d4.y), duf(d4.z), duf(d4.w));
-                    }
-                }
-                /* the casts no bin had room for (a full bin; rare once the plan has a batch of history) */
-                if (__builtin_amdgcn_ballot_w64(pending != 0u) != 0ull) {
-                    for (uint32_t l = 0; l < nl; ++l) {
-                        const bool need = ((pending >> l) & 1u) != 0u;
-                        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-                        const auto &L = uniform_ref(sc.lights + l);
-                        const V3 l_origin = v3(L.origin[0], L.origin[1], L.origin[2]);
-                        V3 direction;
-                        if (L.kind == RT_LIGHT_DIRECTIONAL) direction = v3(L.direction[0], L.direction[1], L.direction[2]);
-                        else direction = normalize(pos - l_origin);
-                        Ray req;
-                        req.o = pos;
-                        req.d = -direction;
-                        req.mode = FACE_BACK;
-                        req.excl = pack_excl(prim, FACE_BACK);
-                        CastResult cr;
-                        cr.prim = -1;
-                        cr.t = 0.0f;
-                        cr.bf = 0u;
-                        cr.a0 = cr.a1 = cr.a2 = 0.0f;
-                        if (need) cr = cast_asm(sc, req);
-                        if (need) {
-                            casts += 1u;
-                            bool lit = true;
-                            if (cr.prim >= 0) {
-                                const bool has_origin = (L.kind != RT_LIGHT_DIRECTIONAL) || (L.has_origin != 0u);
-                                if (has_origin) {
-                                    const V3 occ = req.o + req.d * cr.t;
-                                    if (distance(pos, occ) < distance(pos, l_origin)) lit = false;
-                                } else {
-                                    lit = false;
-                                }
-                            }
-                            if (lit) lit_by |= 1u << l;
-                        }
-                    }
-                }
-                const Mat m = material_approx(sc.materials[obj], u, v); /* the colours only: its normal is not evaluated */
-                V3 sum = v3(0.0f, 0.0f, 0.0f);
-                for (uint32_t l = 0; l < nl; ++l) { /* wave-uniform; the lights in order */
-                    const bool lit = ((lit_by >> l) & 1u) != 0u;
-                    if (__builtin_amdgcn_ballot_w64(lit) == 0ull) continue;
-                    if (lit) {
-                        DirLight dl;
-                        dl.direction = dl.color = v3(0.0f, 0.0f, 0.0f);
-                        (void)approximate_into_directional(uniform_ref(sc.lights + l), pos, &dl); /* the light asked (prepare): Some */
-                        const V3 light_direction = -dl.direction;
-                        const V3 diffuse = get_diffuse(m, adj_n, light_direction) * dl.color;
-                        const V3 specular = get_specular(m, adj_n, -view, light_direction) * dl.color;
-                        sum = sum + diffuse * (1.0f - m.shiness) + specular * m.shiness; /* main.rs:458-461 */
-                    }
-                }
-                if (active) dp.sp_shade[at] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-            }
-        }
-    }
     if (dp.ray_count != nullptr) {
         for (int off = 32; off > 0; off >>= 1) casts += __shfl_down(casts, off, 64);
         if (lane == 0u && casts != 0u) atomicAdd(dp.ray_count, (unsigned long long)casts);
@@ -1768,29 +1378,13 @@ hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const
 }
 
 /* ... and what only reads its records: the shade kernel and the unwind */
-hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream, const hipEvent_t *ev) {
+hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream, const hipEvent_t *ev) {
     const uint32_t total = fr.cols * fr.rows;
     if (total == 0u || dp.n_epochs == 0u) return hipSuccess;
     const size_t n_samples = (size_t)total * dp.n_epochs;
     const uint32_t slots = (uint32_t)(fr.max_depth > 0 ? fr.max_depth : 0) + 1u;
-    /* the shadow rays binned over the batch (dist_bin_*) when the caller has room for the bins, the lights fit a request's result
-     * word and a request's index fits 32 bits; A/B: RT_AMD_SHADE_KERNEL=0 */
-    const bool binned = dp.bin_ctrl != nullptr && sc.n_lights >= 1u && sc.n_lights <= DIST_BIN_MAX_LIGHTS && slots <= 256u &&
-                        n_samples * slots < (1ull << 32) && option(OPT_SHADE_KERNEL, 1) != 0;
-    if (ev != nullptr) (void)hipEventRecord(ev[0], stream); /* profiling: [0, 1] around the shade stage, [2, 3] around the unwind */
-    if (binned) {
-        uint32_t cap = 2048u; /* requests a workgroup lists per round: 8 KB of LDS (a tile of 256 samples has 640 on the reference scene) */
-        { const uint32_t t = (uint32_t)option(OPT_SHADE_CAP, 0); if (t >= 64u && t <= 8192u) cap = t & ~63u; }
-        const size_t lds = (DIST_PREP_HDR + (size_t)cap) * sizeof(uint32_t);
-        const size_t groups = (n_samples + DIST_PREP_THREADS - 1u) / DIST_PREP_THREADS;
-        const uint32_t n_bins = sc.n_lights * DIST_BIN_CLASSES;
-        hipLaunchKernelGGL(dist_bin_plan_kernel, dim3(1), dim3(64), 0, stream, dp.bin_ctrl, n_bins, dp.bin_capacity, (uint32_t)(n_samples < 0xffffffffull ? n_samples : 0xffffffffull));
-        hipLaunchKernelGGL(dist_bin_prepare_kernel, dim3((unsigned)groups), dim3(DIST_PREP_THREADS), lds, stream, sc, dp, n_samples, cap, dp.bin_ctrl, dp.bin_ray, dp.bin_at);
-        hipLaunchKernelGGL(dist_bin_index_kernel, dim3(1), dim3(64), 0, stream, dp.bin_ctrl, sc.n_lights, dp.ray_count);
-        const size_t waves = dp.bin_capacity / 64u + (size_t)n_bins * DIST_BIN_SUBS; /* a wave per chunk there can be at most */
-        hipLaunchKernelGGL(dist_bin_cast_kernel, dim3((unsigned)waves), dim3(64), 0, stream, sc, dp, dp.bin_ctrl, dp.bin_ray, dp.bin_at);
-        hipLaunchKernelGGL(dist_bin_finish_kernel, dim3((unsigned)groups), dim3(DIST_PREP_THREADS), lds, stream, sc, dp, n_samples, cap);
-    } else {
+    if (ev != nullptr) (void)hipEventRecord(ev[0], stream); /* profiling: [0, 1] around the shade kernel, [2, 3] around the unwind */
+    {
         uint32_t tile = 256u; /* samples per workgroup (18 KB of LDS at depth 8: six workgroups per CU); the two lists must fit 48 KB */
         uint32_t sort = 1u;
         /* A/B knobs (profiles/README.md) */

@@ -90,8 +90,6 @@ enum Option : int {
     OPT_DIST_STATIC,       /* 1: the one-kernel organisation with one 64-pixel chunk per wave */
     OPT_DIST_CHAIN_WAVES,  /* waves per SIMD of the chain kernel's grid */
     OPT_SHADE_TILE, OPT_SHADE_SORT, /* the per-request shade kernel: samples per workgroup; 0: no bucket sort */
-    OPT_SHADE_KERNEL,      /* 0: the per-request light loop instead of the lights as phases */
-    OPT_SHADE_CAP,         /* requests per round of the lights-as-phases kernel */
     OPT_MULTI_FORCE_STAGE, /* test hook: rt_multi_* stage every band as if it lived on another device */
     OPT_DIST_SPLIT,        /* 0: the one-kernel organisation (rt_set_distributed_split has the last word) */
     OPT_COUNT
@@ -167,20 +165,7 @@ struct DistParams {
      * staggered answers are worth more than they cost — waves that start together stay in step and ask memory together: 1 165 ->
      * 1 126 Msamples/s in 8-epoch calls with every wave's first chunk its own (profiles/r03_ab12.txt) */
     uint32_t own_first_chunk;
-    /* the shade stage with the shadow rays binned over the whole batch (rt_distributed.hip dist_bin_*): a control block of
-     * DIST_BIN_CTRL_WORDS words that lives from batch to batch (it starts zeroed), and the item arrays the bins share — position +
-     * primitive, and the request the ray belongs to — of bin_capacity entries each.  bin_ctrl null: the per-request shade kernel */
-    uint32_t *bin_ctrl;
-    uint4 *bin_ray;
-    uint32_t *bin_at;
-    uint32_t bin_capacity;
 };
-#define DIST_BIN_CTRL_WORDS 2304u
-/* items the bins are given for a batch of n_samples samples: seven per sample (the reference scene needs 6.0: three lights, 2.5
- * requests per sample, a light behind the surface one time in five), 32 K at least; a bin that fills up leaves its casts to the
- * finish kernel, so this sizes speed, not results */
-inline size_t dist_bin_items(size_t n_samples) { return ((n_samples * 7u > 32768u ? n_samples * 7u : 32768u) + 63u) & ~(size_t)63u; }
-#define DIST_BIN_ITEM_BYTES 20u
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
 #define RT_RNG_DEVICE_WORDS 1032u /* the device record: two banks of it (rt_distributed.hip) */
@@ -194,7 +179,7 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
  * the look-ahead for the next batch, and the next batch's chain kernel on another workspace, beside them */
 uint32_t dist_chain_waves(uint32_t resident_waves); /* the chain kernel's grid, at most */
 hipError_t launch_dist_chain(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
-hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream,
+hipError_t launch_dist_shade_unwind(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, hipStream_t stream,
                                     const hipEvent_t *ev = nullptr); /* ev: four events of the caller's, recorded around the shade kernel and around the unwind */
 /* order[] <- the pixels 0 .. n-1 grouped by cost[] (clipped to 255), dearest first; scratch: 512 words */
 hipError_t launch_dist_pixel_order(const uint32_t *cost, uint32_t *order, uint32_t n_pixels, uint32_t *scratch, hipStream_t stream);
