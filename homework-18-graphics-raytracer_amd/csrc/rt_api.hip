@@ -20,14 +20,11 @@ static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
 #endif
 
-#ifndef RT_LANE_WALK_TRIANGLES_DEFAULT
-#define RT_LANE_WALK_TRIANGLES_DEFAULT 65536
-#endif
 /* the switches of rt_kernels.h `Option`: name (also the environment variable that seeds it), whether it has a value, the value */
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
     "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
     "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
-    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_LANE_WALK_TRIANGLES"};
+    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT"};
 static std::atomic<int> g_opt_set[rt::OPT_COUNT];
 static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
 static std::once_flag g_opt_once;
@@ -272,12 +269,6 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.heads = reinterpret_cast<const rt::DevTriHead *>(base + off_heads);
     sc->ks.light_aux = reinterpret_cast<const rt::LightAux *>(base + off_light_aux);
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
-    /* Beyond this many triangles (128 B each; 4 MB of L2 per XCD) the wave-uniform walk waits for memory one record at a time and
-     * the lane-by-lane walk takes over (rt_cast.h cast_lanes; profiles/r04_scene_sweep_*.jsonl has the crossover) */
-    {
-        const long long at = rt::option(rt::OPT_LANE_WALK_TRIANGLES, RT_LANE_WALK_TRIANGLES_DEFAULT);
-        sc->ks.lane_walk = at > 0 && (long long)desc->n_triangles >= at ? 1u : 0u;
-    }
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
     if (e != hipSuccess || cus <= 0) cus = 256;

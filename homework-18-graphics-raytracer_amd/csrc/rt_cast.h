@@ -754,70 +754,6 @@ __device__ __forceinline__ CastResult cast_pairs(const Scene &sc, const Ray &ray
     return cr;
 }
 
-/* ---- World::cast with every LANE walking the node array for its own ray (round 4: scenes beyond the caches) -----------------
- * cast_asm walks the nodes wave-uniformly: one record — a node, a triangle — per scalar fetch, the next fetch issued a record
- * ahead.  While the scene sits in the scalar cache or the L2 that is the cheapest form there is (every operand in an SGPR).  A
- * scene of tens of megabytes does not: a wave-cast of the 147 484-triangle scene of tools/scene_sweep.py visits a few thousand
- * records, each a round trip to memory of a microsecond and more with ONE in flight per wave — 485 ms for a 480 x 270 frame, the
- * SIMDs idle (profiles/r03_scene_sweep_flat.jsonl).  And the wave visits the UNION of what its 64 rays need.
- *
- * Here each lane walks the same pre-order node array with its own index: a node it can skip — cluster_skippable_lane, the
- * per-lane form of the same conservative test — is left at skip_to, a leaf's triangles are tested one per step with the
- * reference's single-triangle test (the C++ loop of cast<> above: culling, exclusion, t, t <= 0, the three signed areas, the
- * sequential nearest rule `replace unless nearest_t < t`), in index order as the reference visits them.  64 independent fetches
- * are in flight per wave, and a lane pays for its own ray's nodes only.  Same operations on the same values per (ray, triangle)
- * as the wave-uniform loop (which the tests hold equal to the oracle through render variant 3, the same C++ test): bit-identical.
- * The plane sharing and the per-triangle bounding-circle rejection of the asm loop are savings, not results, and are left out.
- * Called like cast_asm: by the lanes that have a ray. */
-template <class Scene>
-__device__ __forceinline__ CastResult cast_lanes(const Scene &sc, const Ray &ray) {
-    const CastMasks m = cast_masks(ray, sc.filter_origin2);
-    const bool cull_back = ray.mode == FACE_FRONT;  /* skip backfaces  (main.rs:185) */
-    const bool cull_front = ray.mode == FACE_BACK;  /* skip frontfaces (main.rs:186) */
-    const bool ex_some = (ray.excl >> 31) != 0u;
-    const uint32_t ex_prim = ray.excl & 0x1fffffffu;
-    const uint32_t ex_face = (ray.excl >> 29) & 3u;
-    float best_t = rtdm::quiet_nan(); /* NaN while None: `best_t < t` is false, as for Option::None */
-    int32_t best_prim = -1;
-    const uint32_t n_nodes = sc.n_segments;
-    uint32_t k = 0u, tri = 0u, tri_end = 0u;
-    while (tri < tri_end || k < n_nodes) {
-        if (tri < tri_end) { /* one triangle of the leaf this lane is in (main.rs:184-233) */
-            const uint32_t i = tri;
-            tri += 1u;
-            const DevTri &T = sc.tris[i];
-            const V3 n = v3(T.n[0], T.n[1], T.n[2]);
-            const float nd = dot(n, ray.d);
-            const bool bf = nd > 0.0f; /* Triangle::backface, primitives.rs:44-46 */
-            if (bf ? cull_back : cull_front) continue;
-            if (ex_some && ex_prim == i) { /* main.rs:190-200 */
-                const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
-                if (criteria) continue;
-            }
-            const float t = (T.d - dot(n, ray.o)) / nd; /* main.rs:203-204 */
-            if (t <= 0.0f) continue;                     /* NaN passes, as in the reference */
-            const V3 p = ray.o + ray.d * t;
-            const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
-            const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
-            const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
-            if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue; /* NaN areas pass (main.rs:224) */
-            if (best_t < t) continue;                          /* ties: the later primitive wins */
-            best_t = t;
-            best_prim = (int32_t)i;
-        } else { /* the next node of this lane's walk */
-            const DevSegment &g = sc.segments[k];
-            const uint32_t count = g.count;
-            if (g.n_normals != 0u && cluster_skippable_lane(g, ray, m)) {
-                k = g.skip_to; /* nothing below can be hit by this ray */
-            } else {
-                if (count != 0u) { tri = g.first; tri_end = g.first + count; }
-                k += 1u;
-            }
-        }
-    }
-    return cast_finish(sc, ray, best_t, best_prim); /* the winner's backface flag and areas re-evaluated: the same operations */
-}
-
 /* What the state machine keeps of a Hit (main.rs:139-147). */
 struct HitGeom {
     V3 pos, normal;

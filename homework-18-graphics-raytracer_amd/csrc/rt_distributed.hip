@@ -897,12 +897,22 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
     const V3 cam_t = v3(fr.cam_toward[0], fr.cam_toward[1], fr.cam_toward[2]);
     const V3 cam_o = v3(fr.cam_origin_focus[0], fr.cam_origin_focus[1], fr.cam_origin_focus[2]);
 
-    __shared__ __attribute__((aligned(16))) uint32_t rng_stage[RNG_LDS_SLOTS * 256u]; /* one wave per workgroup */
+    /* one wave per workgroup.  The pair-wise cast's scratch SHARES the refill's staging area — one union, so that the compiler sees the
+     * two views alias — because a generator is refilled between casts, never during one: every refill (rng_open /
+     * refill in start_epoch and rt_dist_advance.inc) completes, LDS traffic included, before the step's cast_pairs call, and the
+     * cast has returned before the next one.  With 8 KB per wave the kernel sits exactly at five waves per SIMD; anything on top
+     * would cost the fifth. */
+    union ChainLds {
+        uint32_t stage[RNG_LDS_SLOTS * 256u];
 #ifndef RT_DIST_NO_PAIRS
-    /* the pair-wise cast's scratch shares the staging area (a generator is refilled between casts, never during one): with
-     * 8 KB per wave the kernel sits exactly at five waves per SIMD, and anything on top would cost the fifth */
-    static_assert(sizeof(PairLds) <= sizeof(rng_stage), "PairLds must fit the staging area");
-    PairLds *const pair_lds = reinterpret_cast<PairLds *>(rng_stage);
+        PairLds pairs;
+#endif
+    };
+    __shared__ __attribute__((aligned(16))) ChainLds chain_lds;
+    uint32_t *const rng_stage = chain_lds.stage;
+#ifndef RT_DIST_NO_PAIRS
+    static_assert(sizeof(PairLds) <= sizeof(chain_lds.stage), "PairLds must fit the staging area");
+    PairLds *const pair_lds = &chain_lds.pairs;
 #endif
     Rng rng;
     rng.rec = rng.st = dp.rng_states;

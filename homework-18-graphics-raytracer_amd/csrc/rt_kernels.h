@@ -50,8 +50,6 @@ struct KernelScene {
     uint32_t n_segments;
     const DevTriHead *heads;    /* plane + bounding sphere per triangle, for the pair-wise tests (rt_cast.h cast_pairs) */
     const LightAux *light_aux;  /* per light: the cosine of a spot light's spread with its margins (rt_shade.h light_asks) */
-    uint32_t lane_walk;         /* != 0: the scene's records are beyond the caches — the kernels that have the form walk the nodes lane by
-                                 * lane (rt_cast.h cast_lanes) instead of wave-uniformly; set by rt_scene_create from the scene's size */
 };
 
 /* frame/tile + the per-frame camera basis of Camera::shoot (main.rs:85-92),
@@ -94,7 +92,6 @@ enum Option : int {
     OPT_SHADE_TILE, OPT_SHADE_SORT, /* the per-request shade kernel: samples per workgroup; 0: no bucket sort */
     OPT_MULTI_FORCE_STAGE, /* test hook: rt_multi_* stage every band as if it lived on another device */
     OPT_DIST_SPLIT,        /* 0: the one-kernel organisation (rt_set_distributed_split has the last word) */
-    OPT_LANE_WALK_TRIANGLES, /* scenes of at least this many triangles are walked lane by lane (0: never); read by rt_scene_create */
     OPT_COUNT
 };
 long long option(Option id, long long unset);

@@ -219,10 +219,7 @@ __device__ unsigned long long pa_phase_stats[32];
 
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read once per tile, and as a
  * by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
-/* PACKED: the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels.
- * LANES: the intersection loop with every lane walking the node array for its own ray (rt_cast.h cast_lanes): scenes whose
- * records no cache holds (rt_kernels.h KernelScene::lane_walk) */
-template <bool PACKED, bool LANES = false>
+template <bool PACKED> /* the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels */
 __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
@@ -619,8 +616,7 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
         if (do_cast) {
-            if (LANES) cr = cast_lanes(sc, req);
-            else cr = cast_asm(sc, req);
+            cr = cast_asm(sc, req);
             casts += 1u;
         }
 #ifdef PA_STATS
@@ -1129,12 +1125,8 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const P
     if (init) hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     if (first_band) record_main_kernel_event(0, stream); /* the pair brackets all bands of a call (one, up to ~8 Mpixel) */
     const size_t lds = pwf_dynamic_lds(pp.node_cap, pp.ring_cap);
-    const bool packed = pa_ready_packed(pp.node_cap, pp.ring_cap);
-    if (sc.lane_walk != 0u) {
-        if (packed) hipLaunchKernelGGL((pwf_kernel<true, true>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
-        else hipLaunchKernelGGL((pwf_kernel<false, true>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
-    } else if (packed) hipLaunchKernelGGL((pwf_kernel<true, false>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
-    else hipLaunchKernelGGL((pwf_kernel<false, false>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    if (pa_ready_packed(pp.node_cap, pp.ring_cap)) hipLaunchKernelGGL(pwf_kernel<true>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    else hipLaunchKernelGGL(pwf_kernel<false>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
     if (last_band) record_main_kernel_event(1, stream);
     return hipGetLastError();
 }
