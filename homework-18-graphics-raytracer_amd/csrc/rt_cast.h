@@ -523,10 +523,16 @@ __device__ __forceinline__ bool pair_areas(const Scene &sc, const Ray &ray, Pair
 
 #ifdef RT_DIAG_PAIR_TIME
 static __device__ unsigned long long g_pair_time[16];
+static __device__ unsigned long long g_chain_critical[4]; /* over the waves of the launches since the last read: [0] most steps of one wave, [1] longest wave (ticks), [2] waves, [3] - */
 #define RT_DIAG_PAIR_TIME_READER(name)                                                                          \
     extern "C" int name(unsigned long long *out16, int reset) {                                                 \
         if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_pair_time), 16 * sizeof(unsigned long long)) != hipSuccess) return -1; \
         if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_pair_time), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }                                                                                                           \
+    extern "C" int name##_critical(unsigned long long *out4, int reset) {                                       \
+        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rt::g_chain_critical), 4 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_chain_critical), z, sizeof z) != hipSuccess) return -1; } \
         return 0;                                                                                               \
     }
 #define RT_PAIR_TIME_ARG , unsigned long long *dt

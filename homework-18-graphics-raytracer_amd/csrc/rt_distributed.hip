@@ -1060,7 +1060,12 @@ __global__ __launch_bounds__(64, RT_DIST_CHAIN_MIN_WAVES) void dist_chain_kernel
 
 #ifdef RT_DIAG_PAIR_TIME
     diag_dt[8] = __builtin_readcyclecounter() - diag_t0;
-    if (lane == 0u) for (int q = 0; q < 16; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
+    if (lane == 0u) {
+        for (int q = 0; q < 16; ++q) atomicAdd(&g_pair_time[q], diag_dt[q]);
+        atomicMax(&g_chain_critical[0], diag_dt[0]); /* the wave that made the most steps, the wave that ran longest: what a launch cannot be shorter than */
+        atomicMax(&g_chain_critical[1], diag_dt[8]);
+        atomicAdd(&g_chain_critical[2], 1ull);
+    }
 #endif
     if (dp.ray_count != nullptr) {
         uint32_t c = casts;

@@ -65,6 +65,13 @@ __host__ __device__ __forceinline__ bool pa_ready_packed(uint32_t node_cap, uint
     return ((node_cap + 63u) / 64u + 2u * (ring_cap / 64u)) * 4u > PA_READY_UNPACKED_LIMIT;
 }
 __device__ __forceinline__ uint32_t pa_ready_shift(uint32_t idx) { return (idx & 1u) << 4; }
+/* the queue helpers: inlined at every site (46 % of pwf_kernel's instructions); -DPA_OUTLINE makes them functions (A/B:
+ * profiles/r04_ab6.txt) */
+#ifdef PA_OUTLINE
+#define PA_HELPER __device__ __noinline__
+#else
+#define PA_HELPER __device__ __forceinline__
+#endif
 struct PaQueue {
     uint32_t alloc; /* next position to reserve */
     uint32_t taken; /* next PAGE to claim */
@@ -83,7 +90,7 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_a
 /* lane 0 only.  Try to claim the next page of a queue; on success *start is its first position and the return value its
  * item count.  ready[] holds one word per page (index masked for the rings). */
 template <bool PACKED = false>
-__device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
+PA_HELPER uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32_t page_mask, uint32_t min_partial, uint32_t *start) {
     if (PACKED) {
         for (int tries = 0; tries < 4; ++tries) {
             const uint32_t page = lds_load(&q->taken);
@@ -128,7 +135,7 @@ __device__ __forceinline__ uint32_t pa_claim(PaQueue *q, uint32_t *ready, uint32
 
 /* all lanes.  lds_append for a queue of bounded capacity (`capacity` positions, a multiple of 64; `released` counts the pages
  * whose slots may be written again): *ok is false — for the whole wave — when the items do not fit right now. */
-__device__ __forceinline__ uint32_t pa_try_append(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
+PA_HELPER uint32_t pa_try_append(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
     *ok = true;
     if (mask == 0ull) return 0u;
@@ -148,7 +155,7 @@ __device__ __forceinline__ uint32_t pa_try_append(PaQueue *q, const uint32_t *re
 }
 
 /* all lanes.  The same, taking as many of the wave's items as there is room for: *ok is per lane (the first ones in lane order fit) */
-__device__ __forceinline__ uint32_t pa_try_append_some(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
+PA_HELPER uint32_t pa_try_append_some(PaQueue *q, const uint32_t *released, uint32_t capacity, bool want, bool *ok) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
     *ok = false;
     if (mask == 0ull) return 0u;
@@ -173,7 +180,7 @@ __device__ __forceinline__ uint32_t pa_try_append_some(PaQueue *q, const uint32_
 
 /* all lanes.  Publish `want` items written at positions pos.. (as returned by lds_append): add the per-page counts. */
 template <bool PACKED = false>
-__device__ __forceinline__ void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
+PA_HELPER void pa_publish(uint32_t *ready, uint32_t page_mask, bool want, uint32_t pos, uint32_t *gen) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
     if (mask == 0ull) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the items are written before they are counted */

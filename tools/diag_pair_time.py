@@ -42,6 +42,9 @@ if a.burn:
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 assert lib.rt_diag_read_pair_time(buf, 1) == 0
+if hasattr(lib, "rt_diag_read_pair_time_critical"):
+    lib.rt_diag_read_pair_time_critical.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    assert lib.rt_diag_read_pair_time_critical((C.c_ulonglong * 4)(), 1) == 0  # the burn-in is not part of the launch looked at
 rt.render_distributed(scene, cam, frame, rng, a.epochs, accum=accum)
 torch.cuda.synchronize()
 assert lib.rt_diag_read_pair_time(buf, 1) == 0
@@ -53,6 +56,14 @@ if buf[14]:
 if buf[9] or buf[10]:
     step = {9: "fetching work + shoot_focus", 10: "the hit + the level's factor", 12: "the level's draws + scatter_hit | get_refract's exit", 13: "the rest"}
     print("  outside the cast: " + ", ".join(f"{step[k]} {100.0 * buf[k] / max(total, 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in (9, 10, 12, 13)))
+if hasattr(lib, "rt_diag_read_pair_time_critical"):
+    lib.rt_diag_read_pair_time_critical.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    cb = (C.c_ulonglong * 4)()
+    assert lib.rt_diag_read_pair_time_critical(cb, 1) == 0
+    if cb[2]:
+        print(f"  critical path of the launch(es): {cb[2]} waves, {steps / cb[2]:.1f} steps per wave on average, {cb[0]} in the wave that made the most; the longest wave ran {cb[1]} ticks "
+              f"= {cb[1] / max(cb[0], 1):.0f} ticks per step if it is that wave (a wave issues one VALU instruction per four cycles however few of its lanes work: "
+              f"a launch cannot end before its dearest pixels' steps are made, one after the other)")
 print("  of the cast: " + ", ".join(f"{names[k]} {100.0 * buf[k] / max(buf[7], 1):.1f} % ({buf[k] / max(steps, 1):.0f} ticks)" for k in range(1, 7)))
 
 if hasattr(lib, "rt_diag_read_shade_time"):

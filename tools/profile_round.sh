@@ -27,7 +27,12 @@ cd $R
   for k in dist_chain dist_shade dist_unwind rng_prepare rng_scan; do echo "== $k"; python3 tools/pmc_summary.py $O/${TAG}_pmc_scatter --kernel $k; done; } > $O/${TAG}_scatter_pmc.txt
 rm -rf $O/${TAG}_pmc_scatter $O/${TAG}_pmc_scatter.*.log
 if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_need.so ]; then python3 tools/diag_need.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lane_tests_needed.txt; fi
-if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_ptime.so ]; then python3 tools/diag_pair_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chain_step_time.txt; fi
+if [ -f homework-18-graphics-raytracer_amd/variants/librt_amd_ptime.so ]; then
+  python3 tools/diag_pair_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chain_step_time.txt
+  # a 1/8 share: one batch of 16 epochs; its chain kernel cannot end before its dearest pixels' steps are made
+  { echo "# tools/diag_pair_time.py --world 8 --epochs 16 (rank 0's share of an 8-rank job: 259 200 pixels, one pixel per lane)"; python3 tools/diag_pair_time.py --world 8 --epochs 16 2>&1 | grep -v amdgpu.ids
+    echo "# the same share, timed: $(python3 tools/bench_distributed.py --epochs 64 --calls 2 --warm 1 --world 8 2>/dev/null | tail -1 | cut -c1-330)"; } > $O/${TAG}_share_critical_path.txt
+fi
 python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 2>&1 | grep -v amdgpu.ids > $O/${TAG}_whitted_vs_r02.txt
 python3 tools/ab_bench.py --tags r02,main --rounds 7 --frames 10 --world 8 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_whitted_vs_r02.txt
 # (round 2's library lacks entry points this tool binds: its number is in profiles/r02_*)
