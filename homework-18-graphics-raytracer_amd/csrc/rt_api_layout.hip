@@ -371,6 +371,12 @@ int layout_scene(const rt_scene_desc *desc, SceneLayout &layout) {
         d.radius = s.radius;
         d.r2 = s.radius * s.radius; /* radius.powi(2), main.rs:272 */
         d.obj = s.object_index;
+        d.q_miss = std::numeric_limits<float>::infinity();
+        if (std::isfinite(s.radius) && s.radius > 0.0f) {
+            const double up = (double)s.radius * (1.0 + 0x1p-22);
+            const float q = std::nextafter((float)(up * up), std::numeric_limits<float>::infinity());
+            if (std::isfinite(q)) d.q_miss = q;
+        }
     }
     return RT_OK;
 }

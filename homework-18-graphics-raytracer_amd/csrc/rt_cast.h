@@ -349,7 +349,14 @@ __device__ __forceinline__ CastResult cast_finish(const Scene &sc, const Ray &ra
         const auto &S = uniform_ref(sc.spheres + i);
         const V3 c = v3(S.c[0], S.c[1], S.c[2]);
         const V3 disp = c - ray.o;
-        const float lsd = magnitude(cross(disp, ray.d));
+        const V3 cr = cross(disp, ray.d);
+        const float q = dot(cr, cr);
+#ifndef RT_NO_SPHERE_PRETEST /* A/B */
+        /* every lane misses clearly: the correctly rounded root of a q above q_miss is above the radius (the root is monotone;
+         * rt_device_scene.h), which is main.rs:265-268's `continue` — taken before the root.  NaN compares false: not clear. */
+        if (__builtin_amdgcn_ballot_w64(!(q > S.q_miss)) == 0ull) continue;
+#endif
+        const float lsd = rtdm::f_sqrt(q); /* magnitude(cross(disp, ray.d)) */
         if (lsd > S.radius) continue;
         const float tc = dot(ray.d, disp);
         const float k = rtdm::f_sqrt(S.r2 - lsd * lsd);

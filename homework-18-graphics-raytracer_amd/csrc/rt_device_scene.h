@@ -114,7 +114,11 @@ static_assert(sizeof(DevSegment) == 160, "DevSegment layout");
 
 struct alignas(32) DevSphere {
     float c[3]; float radius;
-    float r2;   uint32_t obj; float pad[2];
+    float r2;   uint32_t obj;
+    float q_miss; /* a ray whose squared distance-times-|d| from the centre is above this misses for sure: (radius (1 + 2^-22))^2 rounded
+                   * up — its square root, correctly rounded, is above `radius` — or +inf when the radius is not a positive finite number
+                   * (rt_cast.h cast_finish: a wave all of whose lanes miss that clearly leaves the sphere before the square root) */
+    float pad;
 };
 static_assert(sizeof(DevSphere) == 32, "DevSphere must be 32 bytes");
 

@@ -7,11 +7,11 @@ TAG=${1:-round}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipelined > $O/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pipelined --no-extras > $O/${TAG}_stats.log 2>&1
 cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc/$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stochastic --no-pipelined > $O/${TAG}_pmc.$tag.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc/$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stochastic --no-pipelined --no-extras > $O/${TAG}_pmc.$tag.log 2>&1
   rocprofv3 --pmc $grp --output-format csv -d $O/${TAG}_pmc_dist/$tag -- python3 $R/tools/bench_distributed.py --epochs 64 --calls 1 --warm 1 --fresh 1 > $O/${TAG}_pmc_dist.$tag.log 2>&1
 done
 cd $R
