@@ -5,10 +5,6 @@
  */
 #include "rt_api_internal.h"
 
-#define RT_DIST_MAX_WORKSPACES 3
-#ifndef RT_DIST_WORKSPACES_DEFAULT
-#define RT_DIST_WORKSPACES_DEFAULT 2
-#endif
 #ifndef RT_DIST_SPLIT_DEFAULT
 #define RT_DIST_SPLIT_DEFAULT 1
 #endif
@@ -81,11 +77,11 @@ struct rt_rng {
     /* The shade and unwind kernels of a batch run on a third stream, beside the NEXT batch's chain kernel (two workspaces, used
      * in turn): they fill what its tail leaves idle.  ev_tail[b]: the unwind that read workspace b has finished. */
     hipStream_t tail;
-    hipEvent_t ev_tail[RT_DIST_MAX_WORKSPACES];
+    hipEvent_t ev_tail[2];
     /* the chain kernel's pixels grouped by what their samples cost (rt_kernels.h DistParams::pixel_order): per pixel its cost in the
-     * last batch unwound | up to three orders, one per workspace of a pipelined call | 512 words of scratch */
+     * last batch unwound | two orders, one per workspace of a pipelined call | 512 words of scratch */
     uint32_t *d_pix;
-    bool order_valid[RT_DIST_MAX_WORKSPACES];
+    bool order_valid[2];
     hipStream_t main_stream; /* of the call in progress (for the after-chain hook) */
     uint32_t cols, rows, x0, y0, y_step;
 };
@@ -110,8 +106,9 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     r->aux = nullptr;
     r->ev_chain = r->ev_prepared = nullptr;
     r->tail = nullptr;
-    for (int b = 0; b < RT_DIST_MAX_WORKSPACES; ++b) { r->ev_tail[b] = nullptr; r->order_valid[b] = false; }
+    r->ev_tail[0] = r->ev_tail[1] = nullptr;
     r->d_pix = nullptr;
+    r->order_valid[0] = r->order_valid[1] = false;
     r->ahead = false;
     r->main_stream = nullptr;
     const size_t bytes = (size_t)r->cols * r->rows * RT_RNG_DEVICE_WORDS * sizeof(uint32_t);
@@ -122,13 +119,14 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_states), bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_list), ((size_t)r->cols * r->rows + 1u) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_pix), ((size_t)r->cols * r->rows * (1u + RT_DIST_MAX_WORKSPACES) + 512u) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(r->d_pix, 0, ((size_t)r->cols * r->rows * (1u + RT_DIST_MAX_WORKSPACES) + 512u) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&r->d_pix), ((size_t)r->cols * r->rows * 3u + 512u) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(r->d_pix, 0, ((size_t)r->cols * r->rows * 3u + 512u) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_chain, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_prepared, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->tail, hipStreamNonBlocking); /* (at the lowest stream priority: no different, 1 226 against 1 229 Msamples/s) */
-    for (int b = 0; b < RT_DIST_MAX_WORKSPACES && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&r->ev_tail[b], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_tail[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_tail[1], hipEventDisableTiming);
     if (e == hipSuccess) {
         rt::KernelFrame kf;
         memset(&kf, 0, sizeof kf);
@@ -143,7 +141,7 @@ int rt_rng_create(const rt_frame *frame, rt_rng **out_rng) {
         if (r->ev_chain) (void)hipEventDestroy(r->ev_chain);
         if (r->ev_prepared) (void)hipEventDestroy(r->ev_prepared);
         if (r->aux) (void)hipStreamDestroy(r->aux);
-        for (int b = 0; b < RT_DIST_MAX_WORKSPACES; ++b) if (r->ev_tail[b]) (void)hipEventDestroy(r->ev_tail[b]);
+        for (int b = 0; b < 2; ++b) if (r->ev_tail[b]) (void)hipEventDestroy(r->ev_tail[b]);
         if (r->tail) (void)hipStreamDestroy(r->tail);
         delete r;
         return fail_hip("rt_rng_create", e);
@@ -162,7 +160,7 @@ int rt_rng_destroy(rt_rng *rng) {
     if (rng->ev_chain) (void)hipEventDestroy(rng->ev_chain);
     if (rng->ev_prepared) (void)hipEventDestroy(rng->ev_prepared);
     if (rng->aux) (void)hipStreamDestroy(rng->aux);
-    for (int b = 0; b < RT_DIST_MAX_WORKSPACES; ++b) if (rng->ev_tail[b]) (void)hipEventDestroy(rng->ev_tail[b]);
+    for (int b = 0; b < 2; ++b) if (rng->ev_tail[b]) (void)hipEventDestroy(rng->ev_tail[b]);
     if (rng->tail) (void)hipStreamDestroy(rng->tail);
     delete rng;
     if (e != hipSuccess) return fail_hip("rt_rng_destroy: hipFree", e);
@@ -242,23 +240,19 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         const size_t per_epoch = rt::distributed_split_bytes_per_sample(kf.max_depth) * n_pixels + 4096;
         /* Two workspaces, used in turn, when the call has more than one batch: batch k's shade and unwind kernels then run on a
          * stream of their own beside batch k+1's chain kernel (A/B: RT_AMD_DIST_PIPELINE=0: one workspace, everything in line) */
-        /* RT_AMD_DIST_PIPELINE: how many workspaces a call of several batches uses in turn — 0 / 1: one, everything in line; 2 (the
-         * default; so does any other value) or 3 */
-        const long long pipe_opt = rt::option(rt::OPT_DIST_PIPELINE, RT_DIST_WORKSPACES_DEFAULT);
-        const uint32_t n_want = pipe_opt <= 1 ? 1u : (pipe_opt == 3 ? 3u : 2u);
-        const bool pipeline = n_want > 1u;
+        const bool pipeline = rt::option(rt::OPT_DIST_PIPELINE, 1) != 0;
         /* the chain kernel's pixels grouped by cost when a lane gets two of them at most (rt_kernels.h DistParams::pixel_order);
          * A/B: RT_AMD_DIST_BY_COST=0 never, =1 always */
         const bool small_share = (n_pixels + 63u) / 64u <= 2u * (size_t)rt::dist_chain_waves(dist_waves);
         const bool by_cost = rt::option(rt::OPT_DIST_BY_COST, small_share ? 1 : 0) != 0;
         dp.own_first_chunk = rt::option(rt::OPT_DIST_OWN_FIRST, small_share ? 1 : 0) != 0 ? 1u : 0u; /* rt_kernels.h */
         const bool prep_first = rt::option(rt::OPT_DIST_PREP_FIRST, 1) != 0; /* 0: shade kernel and look-ahead start together */
-        const size_t cap = (size_t)std::max<long long>(0, rt::option(rt::OPT_DIST_WS_MB, 16384 * (long long)n_want)) << 20;
+        const size_t cap = (size_t)std::max<long long>(0, rt::option(rt::OPT_DIST_WS_MB, pipeline ? 32768 : 16384)) << 20;
         uint32_t batch = (uint32_t)std::min<size_t>(std::min<size_t>(n_epochs, 16), std::max<size_t>(1, cap / per_epoch));
         if (pipeline && batch < n_epochs) /* more than one batch: each workspace gets half the cap */
-            batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / n_want / per_epoch));
+            batch = (uint32_t)std::min<size_t>(batch, std::max<size_t>(1, cap / 2u / per_epoch));
         if (batch < n_epochs) batch = (n_epochs + (n_epochs + batch - 1u) / batch - 1u) / ((n_epochs + batch - 1u) / batch); /* as many batches, of equal size */
-        uint32_t n_buf = pipeline && batch < n_epochs ? n_want : 1u;
+        uint32_t n_buf = pipeline && batch < n_epochs ? 2u : 1u;
         size_t o_hdr = 0, o_req = 0, o_shade = 0, o_frame = 0;
         auto layout = [&](uint32_t epochs) { /* -> bytes of ONE workspace */
             auto carve = [](size_t &off, size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
@@ -300,7 +294,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
                     (void)hipGetLastError();
                     ws.d_split = nullptr;
                     if (batch == 1u && n_buf == 1u) break;
-                    if (batch == 1u) n_buf -= 1u;
+                    if (batch == 1u) n_buf = 1u;
                     else batch = (batch + 1u) / 2u;
                     need = total_bytes(batch, n_buf);
                 }
@@ -314,11 +308,11 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
         if (batch >= n_epochs) n_buf = 1u;
         dp.sp_slots = slots;
         uint32_t k = 0;
-        bool tail_used[RT_DIST_MAX_WORKSPACES] = {false, false, false};
+        bool tail_used[2] = {false, false};
         hipError_t e = hipSuccess;
         for (uint32_t e0 = 0; e0 < n_epochs && e == hipSuccess; e0 += batch, ++k) {
             /* the layout is [slot][sample of THIS batch]: a short last batch just uses a prefix of every array */
-            const uint32_t b = k % n_buf;
+            const uint32_t b = n_buf == 2u ? (k & 1u) : 0u;
             char *const ws_base = base + (size_t)b * buf_stride;
             dp.sp_hdr = reinterpret_cast<uint32_t *>(ws_base + o_hdr);
             dp.sp_req = reinterpret_cast<uint4 *>(ws_base + o_req);
@@ -342,7 +336,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             rng->main_stream = stream;
             /* the pixels in the order of what they cost in the batch that used this workspace last (two batches ago in a pipelined
              * call, the last one else): rt_kernels.h DistParams::pixel_order */
-            uint32_t *const pix_cost = rng->d_pix, *const pix_order = rng->d_pix + (size_t)(1u + b) * n_pixels, *const pix_scratch = rng->d_pix + (size_t)(1u + RT_DIST_MAX_WORKSPACES) * n_pixels;
+            uint32_t *const pix_cost = rng->d_pix, *const pix_order = rng->d_pix + (size_t)(1u + b) * n_pixels, *const pix_scratch = rng->d_pix + 3u * n_pixels;
             dp.pixel_cost = by_cost ? pix_cost : nullptr;
             dp.pixel_order = by_cost && rng->order_valid[b] ? pix_order : nullptr;
             if (e == hipSuccess && prof_chain) e = hipEventRecord(pe[2], stream);
@@ -350,7 +344,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             if (e == hipSuccess && prof_chain) e = hipEventRecord(pe[3], stream);
             /* from here on this batch does not touch the RNG records: the look-ahead for the next one, on its own stream */
             if (e == hipSuccess && lookahead && overlap) e = lookahead_after_chain(rng);
-            if (n_buf >= 2u) {
+            if (n_buf == 2u) {
                 if (e == hipSuccess) e = hipEventRecord(rng->ev_tail[b], stream); /* first: the chain kernel has written workspace b ... */
                 if (e == hipSuccess) e = hipStreamWaitEvent(rng->tail, rng->ev_tail[b], 0);
                 /* the next chain kernel waits for the look-ahead, and the look-ahead's workgroups need 64 KB of LDS each: the shade
@@ -375,7 +369,7 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
             if (e == hipSuccess && rng->ahead) e = hipStreamWaitEvent(stream, rng->ev_prepared, 0);
         }
         /* everything the call started is behind the caller's stream again */
-        for (uint32_t b = 0; b < RT_DIST_MAX_WORKSPACES; ++b)
+        for (uint32_t b = 0; b < 2u; ++b)
             if (tail_used[b]) { const hipError_t e2 = hipStreamWaitEvent(stream, rng->ev_tail[b], 0); if (e == hipSuccess) e = e2; }
         if (e != hipSuccess) return fail_hip("rt_render_distributed: launch", e);
         return RT_OK;

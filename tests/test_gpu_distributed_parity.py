@@ -90,7 +90,7 @@ def test_other_scenes_squares_clusters_and_random_triangles(seed):
         assert np.array_equal(rng.download(), st)
 
 
-@pytest.mark.parametrize("pipeline", ["1", "0", "3"])
+@pytest.mark.parametrize("pipeline", ["1", "0"])
 @pytest.mark.parametrize("cap_mb,epochs", [("1", 3), ("8", 3), ("8", 5), ("16", 7)])
 def test_split_pass_in_batches_of_epochs(ctx, organisation, cap_mb, epochs, pipeline):
     """A small workspace cap makes the split pass run the call in batches (1 epoch; 2 + a short last one) — over two workspaces
