@@ -20,11 +20,15 @@ static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
 #endif
 
+#ifndef RT_BFS_WALK_TRIANGLES_DEFAULT
+#define RT_BFS_WALK_TRIANGLES_DEFAULT 32768 /* measured: at 36 892 triangles the breadth-first walk is 14-30 % ahead, at 147 484 3-17x; at 9 244 it
+                                               * wins on flat meshes (-18 %) and loses on spherized ones (+50 %): profiles/r04_scene_sweep_*_bfs.jsonl */
+#endif
 /* the switches of rt_kernels.h `Option`: name (also the environment variable that seeds it), whether it has a value, the value */
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
     "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
     "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
-    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT"};
+    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_BFS_WALK_TRIANGLES"};
 static std::atomic<int> g_opt_set[rt::OPT_COUNT];
 static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
 static std::once_flag g_opt_once;
@@ -220,7 +224,20 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     const size_t off_segments = off_lights + up(desc->n_lights * sizeof(rt_light));
     const size_t off_heads = off_segments + up(segments.size() * sizeof(rt::DevSegment));
     const size_t off_light_aux = off_heads + up(heads.size() * sizeof(rt::DevTriHead));
-    const size_t total = off_light_aux + up(desc->n_lights * sizeof(rt::LightAux)) + 256;
+    /* the node tree as child lists (rt_kernels.h KernelScene::bfs_*): from the pre-order array — the children of an inner node k are
+     * k + 1, then each one's skip_to, up to k's own skip_to; the top-level nodes likewise from 0 */
+    std::vector<uint32_t> bfs_children;
+    std::vector<uint2> bfs_range(segments.size(), make_uint2(0u, 0u));
+    uint32_t bfs_top = 0u;
+    for (uint32_t k = 0; k < (uint32_t)segments.size(); k = segments[k].skip_to) { bfs_children.push_back(k); bfs_top += 1u; }
+    for (uint32_t k = 0; k < (uint32_t)segments.size(); ++k) {
+        if (segments[k].count != 0u) continue; /* a leaf */
+        bfs_range[k].x = (uint32_t)bfs_children.size();
+        for (uint32_t j = k + 1u; j < segments[k].skip_to && j < (uint32_t)segments.size(); j = segments[j].skip_to) { bfs_children.push_back(j); bfs_range[k].y += 1u; }
+    }
+    const size_t off_bfs_children = off_light_aux + up(desc->n_lights * sizeof(rt::LightAux));
+    const size_t off_bfs_range = off_bfs_children + up(bfs_children.size() * sizeof(uint32_t));
+    const size_t total = off_bfs_range + up(bfs_range.size() * sizeof(uint2)) + 256;
     /* a spot light's cone edge as a cosine, with margins (rt_shade.h light_asks); anything unusual switches the shortcut off */
     std::vector<rt::LightAux> light_aux(desc->n_lights);
     for (uint32_t i = 0; i < desc->n_lights; ++i) {
@@ -242,6 +259,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (!segments.empty()) memcpy(&blob[off_segments], segments.data(), segments.size() * sizeof(rt::DevSegment));
     if (!heads.empty()) memcpy(&blob[off_heads], heads.data(), heads.size() * sizeof(rt::DevTriHead));
     if (!light_aux.empty()) memcpy(&blob[off_light_aux], light_aux.data(), light_aux.size() * sizeof(rt::LightAux));
+    if (!bfs_children.empty()) memcpy(&blob[off_bfs_children], bfs_children.data(), bfs_children.size() * sizeof(uint32_t));
+    if (!bfs_range.empty()) memcpy(&blob[off_bfs_range], bfs_range.data(), bfs_range.size() * sizeof(uint2));
 
     rt_scene *sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -269,11 +288,18 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.heads = reinterpret_cast<const rt::DevTriHead *>(base + off_heads);
     sc->ks.light_aux = reinterpret_cast<const rt::LightAux *>(base + off_light_aux);
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
+    sc->ks.bfs_children = reinterpret_cast<const uint32_t *>(base + off_bfs_children);
+    sc->ks.bfs_range = reinterpret_cast<const uint2 *>(base + off_bfs_range);
+    sc->ks.bfs_top = bfs_top;
+    {   /* a scene this large is walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs): node ids must fit 26 bits */
+        const long long at = rt::option(rt::OPT_BFS_WALK_TRIANGLES, RT_BFS_WALK_TRIANGLES_DEFAULT);
+        sc->ks.bfs_walk = at > 0 && (long long)desc->n_triangles >= at && segments.size() < (1u << 26) ? 1u : 0u;
+    }
     int cus = 0;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device);
     if (e != hipSuccess || cus <= 0) cus = 256;
     sc->resident_waves = (uint32_t)cus * 4u * (uint32_t)RT_MIN_WAVES;
-    sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu(7168u, 8192u);
+    sc->pwf_workgroups = (uint32_t)cus * (uint32_t)rt::pwf_workgroups_per_cu(7168u, 8192u, sc->ks.bfs_walk != 0u);
     *out_scene = sc;
     return RT_OK;
 }
@@ -284,6 +310,7 @@ int rt_scene_destroy(rt_scene *scene) {
     for (auto &kv : scene->workspaces) {
         if (kv.second.d_counters) (void)hipFree(kv.second.d_counters);
         if (kv.second.d_pwf) (void)hipFree(kv.second.d_pwf);
+        if (kv.second.d_bfs) (void)hipFree(kv.second.d_bfs);
         if (kv.second.d_split) (void)hipFree(kv.second.d_split);
     }
     if (scene->d_blob) e = hipFree(scene->d_blob);
@@ -400,6 +427,20 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 ws.d_pwf = nullptr;
                 ws.pwf_bytes = 0;
                 ws.pw_ready = false;
+            }
+            if (ws.d_pwf != nullptr && scene->ks.bfs_walk != 0u) { /* the breadth-first walk's item and job lists: per wave of the grid */
+                const size_t words = (size_t)groups * 8u * rt::pwf_bfs_scratch_words_per_wave(); /* PA_WAVES = 8 */
+                if (ws.bfs_words < words) {
+                    if (ws.d_bfs) (void)hipFree(ws.d_bfs);
+                    ws.d_bfs = nullptr;
+                    ws.bfs_words = 0;
+                    if (hipMalloc(reinterpret_cast<void **>(&ws.d_bfs), words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); ws.d_bfs = nullptr; }
+                    else ws.bfs_words = words;
+                }
+                if (ws.d_bfs == nullptr) { (void)hipFree(ws.d_pwf); ws.d_pwf = nullptr; ws.pwf_bytes = 0; ws.pw_ready = false; } /* no room: the per-pixel kernel */
+                pw.bfs_scratch = ws.d_bfs;
+                pw.bfs_items_cap = RT_BFS_ITEMS_CAP;
+                pw.bfs_jobs_cap = RT_BFS_JOBS_CAP;
             }
             if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
             pw.tile_order = g_diag_tile_order.load();

@@ -51,6 +51,8 @@ struct Workspace {
     bool pw_always_prepare = false; /* a call on this stream was captured into a graph: replays come unannounced, so from then on
                                      * every launch prepares its own block and frame description, as a captured one does */
     rt::KernelFrame pw_frame;
+    uint32_t *d_bfs = nullptr; /* persistent-wavefront path on a scene walked breadth-first: item and job lists per wave (rt_kernels.h PwParams) */
+    size_t bfs_words = 0;
     void *d_split = nullptr; /* split distributed pass: requests, shades and frames of one batch of epochs */
     size_t split_bytes = 0;
 };

@@ -767,6 +767,258 @@ __device__ __forceinline__ CastResult cast_pairs(const Scene &sc, const Ray &ray
     return cr;
 }
 
+/* ---- World::cast for scenes beyond the caches: the node tree walked BREADTH-FIRST, ray by ray (round 4) --------------------------
+ * cast_asm visits, wave-uniformly and one record after the other, the UNION of the nodes and triangles its 64 rays need: at 147 484
+ * triangles that is tens of thousands of dependent scalar fetches per wave-cast (485 ms for a 480 x 270 frame), and letting every
+ * lane walk the pre-order array on its own only moves the chain of dependent fetches into the lanes (cast_lanes, round 4: 2-2.5x
+ * slower at every size).  Here nothing waits for anything but its own level:
+ *
+ *   items  (ray, node) pairs, 26 + 6 bits, in a per-wave list in global memory.  Level 0: every active ray x every top-level node.
+ *          A pass takes 64 items, one per lane: the node's record (per-lane loads, all in flight together), the ray from the wave's
+ *          LDS table, cluster_skippable_lane's test.  A node the ray may hit: a LEAF becomes a JOB (ray, leaf); an inner node's
+ *          children — contiguous in KernelScene::bfs_children — become the next level's items (positions by a wave-wide scan).
+ *   jobs   64 at a time, one per lane: the leaf's triangles in index order with the reference's single-triangle test (the C++ loop of
+ *          cast<>: the same operations per (ray, triangle) as everywhere else), the leaf's best candidate under the sequential rule,
+ *          then ONE ds_min_u64 of (bits(t) << 32 | ~index) on the ray's slot: among all accepted candidates of a cast the reference
+ *          ends with the smallest t and, among equal t, the LAST index (main.rs:229-233) — as long as no accepted t is NaN.
+ *   NaN distances (a ray in a triangle's plane: 0 / 0) are the one case where "sequential" and "minimum" part ways; they are handled
+ *   exactly by a second pass over the jobs (see there).  A list that overflows sends the wave through cast_asm.  Visiting a node that could have been skipped is always
+ *   allowed (the skips are conservative), so the test per (ray, node) may be any subset of cluster_skippable_lane's.
+ *
+ * All 64 lanes must be executing (`active` says which have a ray).  One BfsLds and one BfsScratch per wave. */
+struct BfsLds {
+    uint32_t nan_last[64];      /* per ray: 1 + the LAST triangle accepted with a NaN distance (0: none) */
+    unsigned long long key[64]; /* per ray: the smallest (bits(t) << 32 | ~triangle) accepted so far */
+    float4 ro[64];              /* origin, direction.x */
+    float4 rd[64];              /* direction.y, direction.z, flags (mode | filter_ok << 2), exclusion word */
+};
+struct BfsScratch {
+    uint32_t *items_a, *items_b, *jobs;
+    uint32_t items_cap, jobs_cap;
+};
+#ifdef RT_DIAG_BFS /* diagnostic build (tools/diag_bfs.py): [0] wave-casts, [1] sent to cast_asm because a list overflowed, [2] rays with a NaN distance (second pass over the jobs), [3] items,
+                    * [4] jobs, [5] most items in one level, [6] levels, [7] triangle tests (lanes) */
+static __device__ unsigned long long g_bfs_stats[8];
+static __device__ unsigned long long g_bfs_ticks[4]; /* wave cycles: [0] the levels, [1] the jobs, [2] rays cast again (NaN), [3] cast_finish */
+#define RT_DIAG_BFS_READER(name)                                                                                \
+    extern "C" int name(unsigned long long *out8, int reset) {                                                  \
+        if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_bfs_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_bfs_stats), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }                                                                                                           \
+    extern "C" int name##_ticks(unsigned long long *out4, int reset) {                                          \
+        if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(rt::g_bfs_ticks), 4 * sizeof(unsigned long long)) != hipSuccess) return -1; \
+        if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_bfs_ticks), z, sizeof z) != hipSuccess) return -1; } \
+        return 0;                                                                                               \
+    }
+#endif
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t lane, uint32_t *total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= (uint32_t)off) incl += up;
+    }
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return incl - v;
+}
+template <class Scene>
+__device__ __forceinline__ CastResult cast_bfs(const Scene &sc, const Ray &ray, bool active, BfsLds *bl, const BfsScratch &ws) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    CastResult none;
+    none.prim = -1;
+    none.t = 0.0f;
+    none.bf = 0u;
+    none.a0 = none.a1 = none.a2 = 0.0f;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    if (act == 0ull) return none;
+    {   /* this lane's ray where the others can read it */
+        const uint32_t flags = (ray.mode & 3u) | (dot(ray.o, ray.o) <= sc.filter_origin2 ? 4u : 0u);
+        bl->key[lane] = ~0ull;
+        bl->nan_last[lane] = 0u;
+        bl->ro[lane] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+        bl->rd[lane] = make_float4(ray.d.y, ray.d.z, __uint_as_float(flags), __uint_as_float(ray.excl));
+    }
+    pair_sync();
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    uint32_t *list = ws.items_a, *next = ws.items_b;
+    uint32_t n_items = sc.bfs_top * n_act, n_jobs = 0u;
+    bool bad = n_items > ws.items_cap; /* wave-uniform: a list overflowed, or an accepted distance was NaN */
+    if (!bad)
+        for (uint32_t t = 0; t < sc.bfs_top; ++t)
+            if (active) list[t * n_act + my_rank] = (lane << 26) | sc.bfs_children[t];
+#ifdef RT_DIAG_BFS
+    unsigned long long diag_items = n_items, diag_levels = 0ull, diag_tests = 0ull;
+    uint32_t diag_max = n_items;
+    const unsigned long long diag_c0 = __builtin_readcyclecounter();
+#endif
+    while (n_items != 0u && !bad) {
+        uint32_t n_next = 0u;
+        for (uint32_t base = 0; base < n_items && !bad; base += 64u) {
+            const bool have = base + lane < n_items;
+            const uint32_t item = have ? list[base + lane] : 0u;
+            const uint32_t r = item >> 26, k = item & 0x03ffffffu;
+            const float4 a = bl->ro[r], b = bl->rd[r];
+            const V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
+            const DevSegment &g = sc.segments[k];
+            const uint32_t count = g.count, nn = g.n_normals;
+            bool skip = false;
+            if (have && nn != 0u && (__float_as_uint(b.z) & 4u) != 0u) { /* cluster_skippable_lane for ray r */
+                const V3 disp = v3(g.c[0], g.c[1], g.c[2]) - o;
+                const V3 cr = cross(disp, d);
+                const float dd = dot(d, d);
+                if (dot(cr, cr) > g.r2_hi * dd) {
+                    bool steep = true;
+                    if (nn == RT_SEGMENT_CONE) {
+                        const float ad = dot(v3(g.normals[0][0], g.normals[0][1], g.normals[0][2]), d);
+                        steep = ad * ad >= g.normals[0][3] * dd;
+                    } else {
+                        for (uint32_t q = 0; q < nn; ++q)
+                            steep = steep && rtdm::f_abs(dot(v3(g.normals[q][0], g.normals[q][1], g.normals[q][2]), d)) >= 1.0e-3f;
+                    }
+                    skip = steep;
+                }
+            }
+            const bool hit = have && !skip;
+            {   /* a leaf the ray may hit: a job */
+                const bool job = hit && count != 0u;
+                const unsigned long long jm = __builtin_amdgcn_ballot_w64(job);
+                const uint32_t n_j = (uint32_t)__builtin_popcountll(jm);
+                if (n_jobs + n_j > ws.jobs_cap) bad = true;
+                else if (job) ws.jobs[n_jobs + __builtin_amdgcn_mbcnt_hi((uint32_t)(jm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)jm, 0u))] = item;
+                n_jobs += n_j;
+            }
+            {   /* an inner node the ray may hit: its children are the next level's items */
+                const uint2 cr = (hit && count == 0u) ? sc.bfs_range[k] : make_uint2(0u, 0u);
+                uint32_t total = 0u;
+                const uint32_t off = wave_exclusive_scan(cr.y, lane, &total);
+                if (n_next + total > ws.items_cap) bad = true;
+                else for (uint32_t j = 0; j < cr.y; ++j) next[n_next + off + j] = (r << 26) | sc.bfs_children[cr.x + j];
+                n_next += total;
+            }
+        }
+        uint32_t *t = list; list = next; next = t;
+        n_items = n_next;
+#ifdef RT_DIAG_BFS
+        diag_items += n_next; diag_levels += 1ull; if (n_next > diag_max) diag_max = n_next;
+#endif
+    }
+#ifdef RT_DIAG_BFS
+    const unsigned long long diag_c1 = __builtin_readcyclecounter();
+#endif
+    /* The jobs, once for every ray; and — should a ray have accepted a NaN distance (it lies in a triangle's plane: 0 / 0) — once
+     * more for those rays.  The reference's rule "replace unless nearest_t < t" is a minimum only while no accepted t is NaN: a NaN
+     * replaces whatever was nearest, and whatever is accepted next replaces the NaN.  So with L the LAST triangle a ray accepted with
+     * a NaN distance, the ray ends with the minimum over its candidates BEHIND L (index > L) under the usual rule, or, if there are
+     * none, with L itself and its NaN.  Pass 0 finds the minimum over everything and L; pass 1, for the rays that have an L, the
+     * minimum over the candidates behind it. */
+    for (uint32_t pass = 0; pass < 2u && !bad; ++pass) {
+        if (pass == 1u) {
+            const uint32_t mine = bl->nan_last[lane];
+            if (__builtin_amdgcn_ballot_w64(mine != 0u) == 0ull) break; /* no ray met a NaN: the rule was a minimum */
+            if (mine != 0u) bl->key[lane] = ~0ull;
+            pair_sync();
+        }
+        for (uint32_t base = 0; base < n_jobs; base += 64u) {
+            const bool have = base + lane < n_jobs;
+            const uint32_t item = have ? ws.jobs[base + lane] : 0u;
+            const uint32_t r = item >> 26, k = item & 0x03ffffffu;
+            const uint32_t behind = pass == 0u ? 0u : bl->nan_last[r]; /* pass 1: only triangles from this index on, of rays that have one */
+            if (__builtin_amdgcn_ballot_w64(have && (pass == 0u || behind != 0u)) == 0ull) continue;
+            const float4 a = bl->ro[r], b = bl->rd[r];
+            const V3 o = v3(a.x, a.y, a.z), d = v3(a.w, b.x, b.y);
+            const uint32_t mode = __float_as_uint(b.z) & 3u, excl = __float_as_uint(b.w);
+            const bool cull_back = mode == FACE_FRONT, cull_front = mode == FACE_BACK;
+            const bool ex_some = (excl >> 31) != 0u;
+            const uint32_t ex_prim = excl & 0x1fffffffu, ex_face = (excl >> 29) & 3u;
+            const DevSegment &g = sc.segments[k];
+            const bool work = have && (pass == 0u || behind != 0u);
+            uint32_t first = work ? g.first : 0u;
+            const uint32_t last = work ? first + g.count : 0u;
+            if (first < behind) first = behind < last ? behind : last;
+            float best_t = rtdm::quiet_nan();
+            int32_t best_i = -1;
+            uint32_t nan_i = 0u; /* 1 + the last triangle of this leaf accepted with a NaN distance */
+#ifdef RT_DIAG_BFS
+            diag_tests += (unsigned long long)(last - first);
+#endif
+            for (uint32_t i = first; i < last; ++i) { /* main.rs:184-233 for triangle i and ray r */
+                const DevTri &T = sc.tris[i];
+                const V3 n = v3(T.n[0], T.n[1], T.n[2]);
+                const float nd = dot(n, d);
+                const bool bf = nd > 0.0f;
+                if (bf ? cull_back : cull_front) continue;
+                if (ex_some && ex_prim == i) {
+                    const bool criteria = ex_face == FACE_FRONT ? !bf : (ex_face == FACE_BACK ? bf : true);
+                    if (criteria) continue;
+                }
+                const float t = (T.d - dot(n, o)) / nd;
+                if (t <= 0.0f) continue; /* NaN passes, as in the reference */
+                const V3 p = o + d * t;
+                const float a0 = dot(cross(v3(T.e0[0], T.e0[1], T.e0[2]), p - v3(T.v1[0], T.v1[1], T.v1[2])), n);
+                const float a1 = dot(cross(v3(T.e1[0], T.e1[1], T.e1[2]), p - v3(T.v2[0], T.v2[1], T.v2[2])), n);
+                const float a2 = dot(cross(v3(T.e2[0], T.e2[1], T.e2[2]), p - v3(T.v0[0], T.v0[1], T.v0[2])), n);
+                if (a0 < 0.0f || a1 < 0.0f || a2 < 0.0f) continue; /* NaN areas pass (main.rs:224) */
+                if (t != t) { nan_i = i + 1u; continue; } /* accepted with a NaN distance: not a key; it moves L */
+                if (best_t < t) continue;                  /* ties: the later triangle wins */
+                best_t = t;
+                best_i = (int32_t)i;
+            }
+            if (best_i >= 0) atomicMin(&bl->key[r], ((unsigned long long)__float_as_uint(best_t) << 32) | (unsigned long long)(~(uint32_t)best_i));
+            if (nan_i != 0u) atomicMax(&bl->nan_last[r], nan_i);
+        }
+        pair_sync();
+    }
+    const uint32_t my_nan = bad ? 0u : bl->nan_last[lane];
+    const unsigned long long nan_rays = __builtin_amdgcn_ballot_w64(active && my_nan != 0u);
+#ifdef RT_DIAG_BFS
+    const unsigned long long diag_c2 = __builtin_readcyclecounter();
+#endif
+#ifdef RT_DIAG_BFS
+    {
+        unsigned long long tt = diag_tests;
+        for (int off = 32; off > 0; off >>= 1) tt += __shfl_down(tt, off, 64);
+        if (lane == 0u) {
+            atomicAdd(&g_bfs_stats[0], 1ull);
+            if (bad) atomicAdd(&g_bfs_stats[1], 1ull);
+            else if (nan_rays != 0ull) atomicAdd(&g_bfs_stats[2], (unsigned long long)__builtin_popcountll(nan_rays));
+            atomicAdd(&g_bfs_stats[3], diag_items);
+            atomicAdd(&g_bfs_stats[4], (unsigned long long)n_jobs);
+            atomicMax(&g_bfs_stats[5], (unsigned long long)diag_max);
+            atomicAdd(&g_bfs_stats[6], diag_levels);
+            atomicAdd(&g_bfs_stats[7], tt);
+        }
+    }
+#endif
+    if (bad) { /* a list overflowed: the wave-uniform walk, exact whatever happened */
+        CastResult cr = none;
+        if (active) cr = cast_asm(sc, ray);
+        return cr;
+    }
+#ifdef RT_DIAG_BFS
+    const unsigned long long diag_c3 = __builtin_readcyclecounter();
+#endif
+    CastResult cr = none;
+    if (active) {
+        const unsigned long long key = bl->key[lane];
+        float t = rtdm::quiet_nan();
+        int32_t prim = -1;
+        if (key != ~0ull) { t = __uint_as_float((uint32_t)(key >> 32)); prim = (int32_t)(~(uint32_t)key); }
+        else if (my_nan != 0u) prim = (int32_t)(my_nan - 1u); /* nothing behind the last NaN: the ray ends with it (t stays NaN) */
+        cr = cast_finish(sc, ray, t, prim); /* the winner's flag and areas re-evaluated, then the spheres: the same operations */
+    }
+#ifdef RT_DIAG_BFS
+    if (lane == 0u) {
+        atomicAdd(&g_bfs_ticks[0], diag_c1 - diag_c0);
+        atomicAdd(&g_bfs_ticks[1], diag_c2 - diag_c1);
+        atomicAdd(&g_bfs_ticks[2], 0ull);
+        atomicAdd(&g_bfs_ticks[3], __builtin_readcyclecounter() - diag_c3);
+    }
+#endif
+    return cr;
+}
+
 /* What the state machine keeps of a Hit (main.rs:139-147). */
 struct HitGeom {
     V3 pos, normal;

@@ -219,8 +219,23 @@ __device__ unsigned long long pa_phase_stats[32];
 
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read once per tile, and as a
  * by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
-template <bool PACKED> /* the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels */
+/* PACKED: the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels.
+ * BFS: the intersection loop as a breadth-first walk of the node tree, ray by ray (rt_cast.h cast_bfs): scenes beyond the caches
+ * (KernelScene::bfs_walk); 20 KB more LDS per workgroup for the waves' ray tables */
+template <bool PACKED, bool BFS = false>
 __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
+    BfsLds *bfs_lds = nullptr;
+    BfsScratch bfs_ws = {nullptr, nullptr, nullptr, 0u, 0u};
+    if constexpr (BFS) { /* (nothing of this exists in the other instantiation) */
+        __shared__ BfsLds bfs_lds_all[PA_WAVES];
+        bfs_lds = &bfs_lds_all[threadIdx.x >> 6];
+        uint32_t *const mine = pp.bfs_scratch + ((size_t)blockIdx.x * PA_WAVES + (threadIdx.x >> 6)) * (2u * (size_t)pp.bfs_items_cap + pp.bfs_jobs_cap);
+        bfs_ws.items_a = mine;
+        bfs_ws.items_b = mine + pp.bfs_items_cap;
+        bfs_ws.jobs = mine + 2u * (size_t)pp.bfs_items_cap;
+        bfs_ws.items_cap = pp.bfs_items_cap;
+        bfs_ws.jobs_cap = pp.bfs_jobs_cap;
+    }
     extern __shared__ uint32_t pa_ready[]; /* node pages | shade ring pages | refraction ring pages */
     __shared__ PaShared S;
     __shared__ uint4 lds_shade[PA_LQ * PA_LDS_PAGES * PA_SHADE_U4 * 64u];
@@ -615,7 +630,10 @@ __global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const Ker
         cr.t = 0.0f;
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
-        if (do_cast) {
+        if constexpr (BFS) {
+            cr = cast_bfs(sc, req, do_cast, bfs_lds, bfs_ws); /* all lanes: those without a ray help */
+            if (do_cast) casts += 1u;
+        } else if (do_cast) {
             cr = cast_asm(sc, req);
             casts += 1u;
         }
@@ -1077,11 +1095,14 @@ static size_t pwf_dynamic_lds(uint32_t node_cap, uint32_t ring_cap) {
     return (size_t)(PA_READY_WORDS((node_cap + 63u) / 64u, packed) + 2u * PA_READY_WORDS(ring_cap / 64u, packed)) * sizeof(uint32_t);
 }
 
-int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap) {
+int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap, bool bfs_walk) {
     int n = 0;
     const size_t lds = pwf_dynamic_lds(node_cap, ring_cap);
-    const hipError_t e = pa_ready_packed(node_cap, ring_cap) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<true>, (int)PA_THREADS, lds)
-                                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<false>, (int)PA_THREADS, lds);
+    const bool packed = pa_ready_packed(node_cap, ring_cap);
+    const hipError_t e = bfs_walk ? (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<true, true>, (int)PA_THREADS, lds)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<false, true>, (int)PA_THREADS, lds))
+                                  : (packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<true, false>, (int)PA_THREADS, lds)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwf_kernel<false, false>, (int)PA_THREADS, lds));
     if (e != hipSuccess || n < 1) n = 1;
     return n;
 }
@@ -1125,8 +1146,12 @@ hipError_t launch_pwf(const KernelScene &sc, KernelFrame fr, float *out, const P
     if (init) hipLaunchKernelGGL(pwf_init_kernel, dim3(1), dim3(64), 0, stream, pp.global, const_cast<KernelFrame *>(pp.frame), fr);
     if (first_band) record_main_kernel_event(0, stream); /* the pair brackets all bands of a call (one, up to ~8 Mpixel) */
     const size_t lds = pwf_dynamic_lds(pp.node_cap, pp.ring_cap);
-    if (pa_ready_packed(pp.node_cap, pp.ring_cap)) hipLaunchKernelGGL(pwf_kernel<true>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
-    else hipLaunchKernelGGL(pwf_kernel<false>, dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    const bool packed = pa_ready_packed(pp.node_cap, pp.ring_cap);
+    if (sc.bfs_walk != 0u && pp.bfs_scratch != nullptr) {
+        if (packed) hipLaunchKernelGGL((pwf_kernel<true, true>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+        else hipLaunchKernelGGL((pwf_kernel<false, true>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    } else if (packed) hipLaunchKernelGGL((pwf_kernel<true, false>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
+    else hipLaunchKernelGGL((pwf_kernel<false, false>), dim3(workgroups), dim3(PA_THREADS), lds, stream, sc, pp, out);
     if (last_band) record_main_kernel_event(1, stream);
     return hipGetLastError();
 }
@@ -1138,4 +1163,7 @@ RT_DIAG_STAGE_READER(rt_diag_read_stages_pwf)
 #endif
 #ifdef RT_DIAG_NEED
 RT_DIAG_NEED_READER(rt_diag_read_need_pwf)
+#endif
+#ifdef RT_DIAG_BFS
+RT_DIAG_BFS_READER(rt_diag_read_bfs)
 #endif

@@ -83,3 +83,24 @@ def test_rt_render_renders_a_scene_file(tmp_path):
     done = subprocess.run([exe] + common + ["--out", str(b), "--scene", str(f)], capture_output=True, text=True, timeout=120)
     assert done.returncode == 0, done.stderr
     assert a.read_bytes() == b.read_bytes()
+
+
+@pytest.mark.parametrize("level,spherize", [(0, False), (2, True), (3, False)])
+def test_breadth_first_walk_equals_the_oracle(tmp_path, level, spherize):
+    """rt_cast.h cast_bfs — the node tree walked breadth-first, ray by ray: (ray, node) items level by level, (ray, leaf) jobs, the
+    nearest hit as a minimum over (distance, ~index) keys — the form the persistent wavefront kernel takes for scenes beyond the
+    caches (rt_scene_create: RT_AMD_BFS_WALK_TRIANGLES), forced on here for scenes of every size: the reference scene itself, a
+    spherized mesh (normal cones), a flat one (coplanar pieces, rays parallel to the faces' planes), random scenes with degenerate
+    triangles (NaN distances: the wave falls back to the wave-uniform walk).  Radiance and cast counts against the oracle."""
+    world, cam = _scene(tmp_path, level, spherize)
+    desc = world.desc()
+    with rt.options(RT_AMD_BFS_WALK_TRIANGLES=1):
+        scene = rt.Scene(world)  # the switch is read when the scene is created
+        others = [(rt.Scene(w), w, c) for w, c in ((_scenes.random_world(7, 40, 3), _scenes.camera(7)), (_scenes.clustered_world(3, n_boxes=3), _scenes.camera(3)),
+                                                   (_scenes.squares_world(5), _scenes.axis_camera((0.5, 0.5, 3.0))))]
+    views = [(scene, desc, cam, rt.Frame.full(160, 120, 8)), (scene, desc, _scenes.axis_camera((0.7, 1.0, 3.0)), rt.Frame.full(64, 64, 4))]
+    views += [(sc, w.desc(), c, rt.Frame.full(96, 72, 5)) for sc, w, c in others]
+    for sc, d, camera, frame in views:
+        want, wcasts = _oracle.render_whitted(d, camera, frame)
+        got, casts = rt.render_whitted_numpy(sc, camera, frame)
+        assert _same(got, want) and casts == wcasts

@@ -33,6 +33,7 @@ ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen p
 ap.add_argument("--no-parity", action="store_true")
 ap.add_argument("--out", default=None)
 ap.add_argument("--tile-order", default="default", choices=["default", "image"], help="image: the wavefront kernel takes its 8x8 tiles in image order (rt_diag_set_tile_order) instead of scattered by the golden-section stride: all workgroups then work in one region of the image at a time")
+ap.add_argument("--bfs-walk", type=int, default=None, help="RT_AMD_BFS_WALK_TRIANGLES for the scenes of this run: scenes of at least this many triangles are walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs); 0 never, 1 always; default: the library's")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
@@ -49,6 +50,8 @@ if a.lib:
     _orig = _capi._load
     _capi._load = lambda name: C.CDLL(str(_capi.PKG_DIR / "variants" / f"librt_amd_{a.lib}.so")) if name == "librt_amd.so" else _orig(name)
 lib = _capi.amd_lib()
+if a.bfs_walk is not None:
+    rt.set_option("RT_AMD_BFS_WALK_TRIANGLES", a.bfs_walk)
 cam = rt.reference_camera()
 lines = []
 with tempfile.TemporaryDirectory() as tmp:
@@ -117,7 +120,7 @@ with tempfile.TemporaryDirectory() as tmp:
                    "scene_bytes_device": T * (128 + 64), "scene_file_bytes": path.stat().st_size,
                    "width": W, "height": H, "depth": a.depth, "frames": n, "ms_per_frame": round(ms, 4), "casts_per_frame": casts,
                    "Mrays_per_s": round(casts / ms / 1e3, 2), "Gtri_tests_per_s": round(casts * T / ms / 1e6, 2),
-                   "parity_vs_oracle_small_frame": parity, "tile_order": a.tile_order}
+                   "parity_vs_oracle_small_frame": parity, "tile_order": a.tile_order, "bfs_walk_from_triangles": a.bfs_walk}
             lines.append(rec)
             print(json.dumps(rec), flush=True)
         _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
