@@ -21,8 +21,9 @@ extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = stati
 #endif
 
 #ifndef RT_BFS_WALK_TRIANGLES_DEFAULT
-#define RT_BFS_WALK_TRIANGLES_DEFAULT 32768 /* measured: at 36 892 triangles the breadth-first walk is 14-30 % ahead, at 147 484 3-17x; at 9 244 it
-                                               * wins on flat meshes (-18 %) and loses on spherized ones (+50 %): profiles/r04_scene_sweep_*_bfs.jsonl */
+#define RT_BFS_WALK_TRIANGLES_DEFAULT 8192 /* measured (profiles/r04_scene_sweep_*_bfs.jsonl against *_wave_uniform.jsonl): the breadth-first walk is 1.3-1.7x
+                                              * ahead at 9 244 triangles, 2.1-2.3x at 36 892, 8-17x at 147 484; at 2 332 it loses (1.2x on flat meshes, 2x
+                                              * on spherized ones) */
 #endif
 /* the switches of rt_kernels.h `Option`: name (also the environment variable that seeds it), whether it has a value, the value */
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
@@ -224,20 +225,43 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     const size_t off_segments = off_lights + up(desc->n_lights * sizeof(rt_light));
     const size_t off_heads = off_segments + up(segments.size() * sizeof(rt::DevSegment));
     const size_t off_light_aux = off_heads + up(heads.size() * sizeof(rt::DevTriHead));
-    /* the node tree as child lists (rt_kernels.h KernelScene::bfs_*): from the pre-order array — the children of an inner node k are
-     * k + 1, then each one's skip_to, up to k's own skip_to; the top-level nodes likewise from 0 */
-    std::vector<uint32_t> bfs_children;
-    std::vector<uint2> bfs_range(segments.size(), make_uint2(0u, 0u));
+    /* the node tree once more in LEVEL ORDER (rt_kernels.h KernelScene::bfs_nodes): the top-level nodes first, then every inner node's
+     * children one after the other — an inner node's record then names its children as a range [first, first + skip_to) of the same
+     * array and a breadth-first walk needs no child list beside it.  From the pre-order array: the children of inner node k are
+     * k + 1, then each one's skip_to, up to k's own skip_to; the top-level nodes likewise from 0. */
+    std::vector<rt::DevSegment> bfs_nodes;
     uint32_t bfs_top = 0u;
-    for (uint32_t k = 0; k < (uint32_t)segments.size(); k = segments[k].skip_to) { bfs_children.push_back(k); bfs_top += 1u; }
-    for (uint32_t k = 0; k < (uint32_t)segments.size(); ++k) {
-        if (segments[k].count != 0u) continue; /* a leaf */
-        bfs_range[k].x = (uint32_t)bfs_children.size();
-        for (uint32_t j = k + 1u; j < segments[k].skip_to && j < (uint32_t)segments.size(); j = segments[j].skip_to) { bfs_children.push_back(j); bfs_range[k].y += 1u; }
+    {
+        std::vector<uint32_t> order; /* pre-order index of the node at each level-order position */
+        order.reserve(segments.size());
+        for (uint32_t k = 0; k < (uint32_t)segments.size(); k = segments[k].skip_to) { order.push_back(k); bfs_top += 1u; }
+        bfs_nodes.reserve(segments.size());
+        for (size_t at = 0; at < order.size(); ++at) {
+            const uint32_t k = order[at];
+            rt::DevSegment g = segments[k];
+            if (g.count == 0u) { /* inner: first = its first child's position, skip_to = how many */
+                g.first = (uint32_t)order.size();
+                g.skip_to = 0u;
+                for (uint32_t j = k + 1u; j < segments[k].skip_to && j < (uint32_t)segments.size(); j = segments[j].skip_to) { order.push_back(j); g.skip_to += 1u; }
+            }
+            bfs_nodes.push_back(g);
+        }
     }
-    const size_t off_bfs_children = off_light_aux + up(desc->n_lights * sizeof(rt::LightAux));
-    const size_t off_bfs_range = off_bfs_children + up(bfs_children.size() * sizeof(uint32_t));
-    const size_t total = off_bfs_range + up(bfs_range.size() * sizeof(uint2)) + 256;
+    /* ... and what the walk reads of every node and every triangle as arrays of 16-byte pieces (KernelScene::bfs_soa): the lanes of a
+     * pass hold consecutive nodes or triangles, so each of its loads is one contiguous kilobyte */
+    std::vector<float> bfs_soa((3u * bfs_nodes.size() + 2u * heads.size()) * 4u, 0.0f);
+    for (size_t k = 0; k < bfs_nodes.size(); ++k) {
+        memcpy(&bfs_soa[4u * k], &bfs_nodes[k], 16);                                /* first, count, n_normals, r2_hi */
+        memcpy(&bfs_soa[4u * (bfs_nodes.size() + k)], &bfs_nodes[k].c[0], 16);       /* centre, child count */
+        memcpy(&bfs_soa[4u * (2u * bfs_nodes.size() + k)], &bfs_nodes[k].normals[0][0], 16); /* the first plane direction, or the cone */
+    }
+    for (size_t t = 0; t < heads.size(); ++t) {
+        memcpy(&bfs_soa[4u * (3u * bfs_nodes.size() + t)], &heads[t].n[0], 16);                  /* plane */
+        memcpy(&bfs_soa[4u * (3u * bfs_nodes.size() + heads.size() + t)], &heads[t].bc[0], 16);  /* bounding sphere */
+    }
+    const size_t off_bfs_nodes = off_light_aux + up(desc->n_lights * sizeof(rt::LightAux));
+    const size_t off_bfs_soa = off_bfs_nodes + up(bfs_nodes.size() * sizeof(rt::DevSegment));
+    const size_t total = off_bfs_soa + up(bfs_soa.size() * sizeof(float)) + 256;
     /* a spot light's cone edge as a cosine, with margins (rt_shade.h light_asks); anything unusual switches the shortcut off */
     std::vector<rt::LightAux> light_aux(desc->n_lights);
     for (uint32_t i = 0; i < desc->n_lights; ++i) {
@@ -259,8 +283,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     if (!segments.empty()) memcpy(&blob[off_segments], segments.data(), segments.size() * sizeof(rt::DevSegment));
     if (!heads.empty()) memcpy(&blob[off_heads], heads.data(), heads.size() * sizeof(rt::DevTriHead));
     if (!light_aux.empty()) memcpy(&blob[off_light_aux], light_aux.data(), light_aux.size() * sizeof(rt::LightAux));
-    if (!bfs_children.empty()) memcpy(&blob[off_bfs_children], bfs_children.data(), bfs_children.size() * sizeof(uint32_t));
-    if (!bfs_range.empty()) memcpy(&blob[off_bfs_range], bfs_range.data(), bfs_range.size() * sizeof(uint2));
+    if (!bfs_nodes.empty()) memcpy(&blob[off_bfs_nodes], bfs_nodes.data(), bfs_nodes.size() * sizeof(rt::DevSegment));
+    if (!bfs_soa.empty()) memcpy(&blob[off_bfs_soa], bfs_soa.data(), bfs_soa.size() * sizeof(float));
 
     rt_scene *sc = new (std::nothrow) rt_scene();
     if (!sc) return fail(RT_ERR_OUT_OF_MEMORY, "rt_scene_create: host allocation failed");
@@ -288,8 +312,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.heads = reinterpret_cast<const rt::DevTriHead *>(base + off_heads);
     sc->ks.light_aux = reinterpret_cast<const rt::LightAux *>(base + off_light_aux);
     sc->ks.filter_origin2 = (float)(16.0 * scene_extent * scene_extent); /* |origin| <= 4 x extent */
-    sc->ks.bfs_children = reinterpret_cast<const uint32_t *>(base + off_bfs_children);
-    sc->ks.bfs_range = reinterpret_cast<const uint2 *>(base + off_bfs_range);
+    sc->ks.bfs_nodes = reinterpret_cast<const rt::DevSegment *>(base + off_bfs_nodes);
+    sc->ks.bfs_soa = reinterpret_cast<const float4 *>(base + off_bfs_soa);
     sc->ks.bfs_top = bfs_top;
     {   /* a scene this large is walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs): node ids must fit 26 bits */
         const long long at = rt::option(rt::OPT_BFS_WALK_TRIANGLES, RT_BFS_WALK_TRIANGLES_DEFAULT);

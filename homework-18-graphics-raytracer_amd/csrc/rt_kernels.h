@@ -50,11 +50,14 @@ struct KernelScene {
     uint32_t n_segments;
     const DevTriHead *heads;    /* plane + bounding sphere per triangle, for the pair-wise tests (rt_cast.h cast_pairs) */
     const LightAux *light_aux;  /* per light: the cosine of a spot light's spread with its margins (rt_shade.h light_asks) */
-    /* the node tree once more, as child lists: bfs_children[bfs_range[k].x .. + bfs_range[k].y) are the children of inner node k
-     * (indices into `segments`), bfs_children[0 .. bfs_top) the top-level nodes — what a breadth-first walk needs (rt_cast.h
-     * cast_bfs).  bfs_walk != 0: the scene is large enough for the kernels that have that walk to use it (rt_scene_create) */
-    const uint32_t *bfs_children;
-    const uint2 *bfs_range;
+    /* the node tree once more, in level order: bfs_nodes[0 .. bfs_top) are the top-level nodes, and an INNER node's record names its
+     * children as bfs_nodes[first .. first + skip_to) (a leaf's first / count are its triangles, as in `segments`) — what a
+     * breadth-first walk needs (rt_cast.h cast_bfs).  bfs_walk != 0: the scene is large enough for the kernels that have that walk to
+     * use it (rt_scene_create) */
+    const DevSegment *bfs_nodes;
+    /* the same once more as arrays of 16-byte pieces, one after the other: n_segments x (first, count, n_normals, r2_hi), n_segments x
+     * (centre, child count), n_segments x (the first plane direction or the cone), n_triangles x plane, n_triangles x bounding sphere */
+    const float4 *bfs_soa;
     uint32_t bfs_top, bfs_walk;
 };
 
@@ -130,14 +133,14 @@ struct PwParams {
     uint32_t tile_reserve;  /* nodes an arena must have free per primary ray before it takes more tiles */
     uint32_t tile_stride;   /* the k-th tile handed out is (k * tile_stride) mod n_tiles; coprime to n_tiles */
     const uint32_t *tile_order; /* or, when set, tile_order[k] (n_tiles entries, a permutation) */
-    /* the breadth-first walk's scratch (scenes with KernelScene::bfs_walk): per wave of the grid two item lists of bfs_items_cap words
-     * and a job list of bfs_jobs_cap words, one after the other */
+    /* the breadth-first walk's scratch (scenes with KernelScene::bfs_walk): per wave of the grid two level lists of bfs_items_cap
+     * records (two words each) and a job list of bfs_jobs_cap records, one after the other */
     uint32_t *bfs_scratch;
     uint32_t bfs_items_cap, bfs_jobs_cap;
 };
-#define RT_BFS_ITEMS_CAP 262144u
+#define RT_BFS_ITEMS_CAP 32768u
 #define RT_BFS_JOBS_CAP 131072u
-inline size_t pwf_bfs_scratch_words_per_wave() { return 2u * (size_t)RT_BFS_ITEMS_CAP + RT_BFS_JOBS_CAP; }
+inline size_t pwf_bfs_scratch_words_per_wave() { return 4u * (size_t)RT_BFS_ITEMS_CAP + 2u * (size_t)RT_BFS_JOBS_CAP; }
 int pwf_workgroups_per_cu(uint32_t node_cap, uint32_t ring_cap, bool bfs_walk = false);
 size_t pwf_arena_bytes(uint32_t node_cap, uint32_t ring_cap);
 /* init: zero this launch's block of global words and (re)write the frame description first — needed for a workspace's first

@@ -223,13 +223,13 @@ __device__ unsigned long long pa_phase_stats[32];
  * BFS: the intersection loop as a breadth-first walk of the node tree, ray by ray (rt_cast.h cast_bfs): scenes beyond the caches
  * (KernelScene::bfs_walk); 20 KB more LDS per workgroup for the waves' ray tables */
 template <bool PACKED, bool BFS = false>
-__global__ __launch_bounds__(PA_THREADS, PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
+__global__ __launch_bounds__(PA_THREADS, BFS ? 2 : PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {
     BfsLds *bfs_lds = nullptr;
     BfsScratch bfs_ws = {nullptr, nullptr, nullptr, 0u, 0u};
     if constexpr (BFS) { /* (nothing of this exists in the other instantiation) */
         __shared__ BfsLds bfs_lds_all[PA_WAVES];
         bfs_lds = &bfs_lds_all[threadIdx.x >> 6];
-        uint32_t *const mine = pp.bfs_scratch + ((size_t)blockIdx.x * PA_WAVES + (threadIdx.x >> 6)) * (2u * (size_t)pp.bfs_items_cap + pp.bfs_jobs_cap);
+        uint2 *const mine = reinterpret_cast<uint2 *>(pp.bfs_scratch) + ((size_t)blockIdx.x * PA_WAVES + (threadIdx.x >> 6)) * (2u * (size_t)pp.bfs_items_cap + pp.bfs_jobs_cap);
         bfs_ws.items_a = mine;
         bfs_ws.items_b = mine + pp.bfs_items_cap;
         bfs_ws.jobs = mine + 2u * (size_t)pp.bfs_items_cap;

@@ -87,11 +87,13 @@ def test_rt_render_renders_a_scene_file(tmp_path):
 
 @pytest.mark.parametrize("level,spherize", [(0, False), (2, True), (3, False)])
 def test_breadth_first_walk_equals_the_oracle(tmp_path, level, spherize):
-    """rt_cast.h cast_bfs — the node tree walked breadth-first, ray by ray: (ray, node) items level by level, (ray, leaf) jobs, the
-    nearest hit as a minimum over (distance, ~index) keys — the form the persistent wavefront kernel takes for scenes beyond the
-    caches (rt_scene_create: RT_AMD_BFS_WALK_TRIANGLES), forced on here for scenes of every size: the reference scene itself, a
+    """rt_cast.h cast_bfs — the node tree walked breadth-first, ray by ray: records of (ray, up to 16 nodes) level by level, jobs of
+    (ray, up to 16 triangles), band jobs for leaves only kept because the ray is nearly parallel to a plane, the nearest hit as a
+    minimum over (distance, ~index) keys — the form the persistent wavefront kernel takes for scenes beyond the caches
+    (rt_scene_create: RT_AMD_BFS_WALK_TRIANGLES), forced on here for scenes of every size: the reference scene itself, a
     spherized mesh (normal cones), a flat one (coplanar pieces, rays parallel to the faces' planes), random scenes with degenerate
-    triangles (NaN distances: the wave falls back to the wave-uniform walk).  Radiance and cast counts against the oracle."""
+    triangles and plain leaves of many triangles, rays in the planes of squares (NaN distances: the second pass over the jobs).
+    Radiance and cast counts against the oracle."""
     world, cam = _scene(tmp_path, level, spherize)
     desc = world.desc()
     with rt.options(RT_AMD_BFS_WALK_TRIANGLES=1):
@@ -104,3 +106,23 @@ def test_breadth_first_walk_equals_the_oracle(tmp_path, level, spherize):
         want, wcasts = _oracle.render_whitted(d, camera, frame)
         got, casts = rt.render_whitted_numpy(sc, camera, frame)
         assert _same(got, want) and casts == wcasts
+
+
+@pytest.mark.parametrize("spherize", [True, False])
+def test_scenes_above_the_switch_take_the_breadth_first_walk(tmp_path, spherize):
+    """9 244 triangles: above rt_scene_create's default switch (RT_AMD_BFS_WALK_TRIANGLES unset), so the wavefront kernel walks the tree
+    breadth-first and the per-pixel kernel wave-uniformly — both against the oracle, the usual camera and the axis-aligned one."""
+    world, cam = _scene(tmp_path, 4, spherize)
+    desc = world.desc()
+    assert desc.n_triangles == 36 * 4 ** 4 + 28
+    scene = rt.Scene(world)
+    lib = _capi.amd_lib()
+    for camera, frame in [(cam, rt.Frame.full(96, 72, 5)), (_scenes.axis_camera((0.7, 1.0, 3.0)), rt.Frame.full(48, 48, 4))]:
+        want, wcasts = _oracle.render_whitted(desc, camera, frame)
+        for variant in (18, 2):
+            _capi.check(lib.rt_set_variant(variant))
+            try:
+                got, casts = rt.render_whitted_numpy(scene, camera, frame)
+            finally:
+                _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
+            assert _same(got, want) and casts == wcasts, (variant, frame.width)

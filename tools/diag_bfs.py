@@ -41,8 +41,8 @@ with tempfile.TemporaryDirectory() as tmp:
         W, H = (960, 540) if level <= 5 else (480, 270)
         frame = rt.Frame.full(W, H, 8)
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-        buf = (C.c_ulonglong * 8)()
-        tk = (C.c_ulonglong * 4)()
+        buf = (C.c_ulonglong * 12)()
+        tk = (C.c_ulonglong * 16)()
         lib.rt_diag_read_bfs(buf, 1)
         lib.rt_diag_read_bfs_ticks(tk, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,5 +54,6 @@ with tempfile.TemporaryDirectory() as tmp:
         lib.rt_diag_read_bfs_ticks(tk, 1)
         n = max(buf[0], 1)
         print(f"level {level} ({world.desc().n_triangles} triangles, {W}x{H}): {buf[0]} wave-casts; {buf[1]} sent to cast_asm for a full list, {buf[2]} rays with an accepted NaN distance (second pass over the jobs); "
-              f"frame {e0.elapsed_time(e1):.1f} ms; wave cycles in the cast: levels {tk[0] / 1e6:.0f} M, jobs {tk[1] / 1e6:.0f} M, cast_finish {tk[3] / 1e6:.0f} M; "
-              f"per wave-cast {buf[3] / n:.0f} items over {buf[6] / n:.1f} levels (most in one level, any wave: {buf[5]}), {buf[4] / n:.0f} jobs, {buf[7] / n:.0f} lane triangle tests")
+              f"frame {e0.elapsed_time(e1):.1f} ms; wave cycles in the cast: levels {tk[0] / 1e6:.0f} M, jobs {tk[1] / 1e6:.0f} M, band jobs {tk[2] / 1e6:.0f} M, cast_finish {tk[3] / 1e6:.0f} M; "
+              f"per wave-cast {buf[3] / n:.0f} (ray, node) pairs over {buf[6] / n:.1f} levels (most records in one level, any wave: {buf[5]}), {buf[4] / n:.0f} jobs with {buf[7] / n:.0f} (ray, triangle) pairs, "
+              f"{buf[8] / n:.0f} band jobs with {buf[9] / n:.0f} pairs, {buf[10] / n:.1f} pairs as far as the signed areas; the longest walk of one wave-cast {buf[11] / 1e6:.2f} M cycles; waiting for memory at the top of a group / the rest: levels {tk[4] / 1e6:.0f} / {tk[5] / 1e6:.0f} M, jobs {tk[6] / 1e6:.0f} / {tk[7] / 1e6:.0f} M, band jobs {tk[8] / 1e6:.0f} / {tk[9] / 1e6:.0f} M; of a band group of 8 passes ({tk[12]} groups): issuing the next group's loads {tk[10] / max(tk[12], 1):.0f} cycles, its records and rays out of LDS {tk[11] / max(tk[12], 1):.0f}, all of it {(tk[8] + tk[9]) / max(tk[12], 1):.0f}")

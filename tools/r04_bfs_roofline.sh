@@ -1,6 +1,6 @@
 #!/bin/bash
 # The breadth-first walk against its roofs (run on the GPU box): tools/r04_bfs_roofline.sh <tag>
-#   levels 5 and 6, flat and spherized, the library's default walk (breadth-first from 32 768 triangles): the frame time, and
+#   levels 5 and 6, flat and spherized, the library's default walk (breadth-first from 8 192 triangles): the frame time, and
 #   rocprofv3 --pmc passes (separate) of rt::pwf_kernel — FETCH_SIZE, WRITE_SIZE (KB; FETCH x2 on gfx950), SQ_INSTS_VALU, SQ_BUSY_CYCLES
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r04}
 OUT=$O/${TAG}_bfs_roofline.txt; : > $OUT

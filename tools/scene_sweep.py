@@ -31,6 +31,7 @@ ap.add_argument("--spherize", action="store_true")
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen per size)")
 ap.add_argument("--no-parity", action="store_true")
+ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("W", "H"), help="timed frame size (default: by scene size, 1920x1080 up to 3000 triangles, 960x540 up to 40000, 480x270 above)")
 ap.add_argument("--out", default=None)
 ap.add_argument("--tile-order", default="default", choices=["default", "image"], help="image: the wavefront kernel takes its 8x8 tiles in image order (rt_diag_set_tile_order) instead of scattered by the golden-section stride: all workgroups then work in one region of the image at a time")
 ap.add_argument("--bfs-walk", type=int, default=None, help="RT_AMD_BFS_WALK_TRIANGLES for the scenes of this run: scenes of at least this many triangles are walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs); 0 never, 1 always; default: the library's")
@@ -87,6 +88,8 @@ with tempfile.TemporaryDirectory() as tmp:
             W, H = 960, 540
         else:
             W, H = 480, 270
+        if a.size:
+            W, H = a.size
         frame = rt.Frame.full(W, H, a.depth)
         d_order = None
         if a.tile_order == "image":
