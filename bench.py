@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument("--no-pipelined", action="store_true", help="skip the extra measurement with two frames in flight (after the headline's timed region)")
     p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
-    p.add_argument("--no-extras", action="store_true", help="skip the sharded_finish and share_timing objects (after everything else)")
+    p.add_argument("--no-extras", action="store_true", help="skip the sharded_finish, share_timing and large_scene objects (after everything else)")
     return p.parse_args()
 
 
@@ -305,6 +305,43 @@ def share_timing(scene, camera, width, height, depth, steps):
         out["shares"][f"1/{n}"] = {"whitted_ms_per_frame": round(w, 4), "dof_ms_per_epoch": round(d, 4),
                                     "speedup_if_all_ranks_alike": {"whitted": round(w1 / w, 2), "dof": round(d1 / d, 2)}}
     return out
+
+
+def large_scene(camera, width, height, depth, levels=6):
+    """the same literal scene around the dodecahedron tessellated 4^levels ways (147 484 triangles at 6: 28 MB of
+    records, beyond every cache), the headline's frame.  rt_scene_create gives such a scene the breadth-first walk of the node tree
+    (rt_cast.h cast_bfs; bit-identical to the oracle at every size: tests/test_gpu_scene_sizes.py, tools/scene_sweep.py).  Timed like
+    the headline, three frames after a warm one; 'algorithmic' triangle tests = casts x triangles, what the reference's loop runs."""
+    import subprocess
+    import tempfile
+
+    import torch
+
+    import homework_18_graphics_raytracer_amd as rt
+
+    with tempfile.TemporaryDirectory() as tmp:
+        obj = Path(tmp) / "dodecahedron.obj"
+        subprocess.run([sys.executable, str(ROOT / "tools" / "make_tessellated_obj.py"), rt.DEFAULT_OBJ, str(obj), "--levels", str(levels)], check=True, capture_output=True)
+        world = rt.reference_world(str(obj))
+    desc = world.desc()
+    scene = rt.Scene(world)
+    frame = rt.Frame.full(width, height, depth)
+    out = torch.empty((height, width, 3), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rt.render_whitted(scene, camera, frame, out=out, ray_count=cnt)
+    torch.cuda.synchronize()
+    casts = int(cnt.item())
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rt.render_whitted(scene, camera, frame, out=out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    return {"workload": f"the reference scene around a dodecahedron of {36 * 4 ** levels} flat triangles ({desc.n_triangles} triangles, {desc.n_triangles * 128 / 1e6:.1f} MB of records), "
+                        f"{width}x{height}, depth {depth}, Whitted pass, breadth-first walk of the node tree",
+            "ms_per_frame": round(ms, 3), "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_frame": casts,
+            "algorithmic_T_triangle_tests_per_s": round(casts * desc.n_triangles / ms / 1e9, 2),
+            "parity": "tests/test_gpu_scene_sizes.py (forced on at every size), tools/scene_sweep.py at this size on a small frame (profiles/r04_scene_sweep_flat_bfs.jsonl)"}
 
 
 def sharded_finish(band, height, rank, world_size, distributed, steps):
@@ -589,17 +626,20 @@ def main() -> int:
         scatter = stochastic_pass(scene, camera, W, H, D, rank, world_size, distributed, world_desc=None, epochs=SCATTER_EPOCHS,
                                   config="configs[4], the scatter pass", traffic_file="traffic_scatter.json")
     # after everything else: what the frame costs AFTER rendering when its bands stay sharded, and what a share of either pass costs
-    finish, shares = None, None
+    finish, shares, large = None, None, None
     if not args.no_extras:
         finish = sharded_finish(band if not distributed else pipe.band(0), H, rank, world_size, distributed, min(args.steps, 20))
         if world_size == 1 and not distributed:
             shares = share_timing(scene, camera, W, H, D, min(args.steps, 20))
+            large = large_scene(camera, W, H, D)
     status = 0
     if rank == 0:
         if finish is not None:
             line["sharded_finish"] = finish
         if shares is not None:
             line["share_timing"] = shares
+        if large is not None:
+            line["large_scene"] = large
         if pipelined is not None:
             line["pipelined"] = pipelined
         if stochastic is not None:
