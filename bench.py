@@ -46,6 +46,9 @@ def parse_args():
     p.add_argument("--no-pipelined", action="store_true", help="skip the extra measurement with two frames in flight (after the headline's timed region)")
     p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
+    p.add_argument("--frames-in-flight", type=int, default=0,
+                   help="N > 1 only: frames a rank renders at once, one per stream (dist.FramePipeline in_flight); 0 = 2 for fewer than 8 ranks, 4 from 8 "
+                        "(a 1/8 share of the frame leaves the GPU mostly idle: profiles/r04_frames_in_flight.txt); 1 = one after the other")
     p.add_argument("--no-extras", action="store_true", help="skip the sharded_finish, share_timing and large_scene objects (after everything else)")
     return p.parse_args()
 
@@ -443,21 +446,30 @@ def main() -> int:
     count = torch.zeros(1, dtype=torch.int64, device="cuda")
     # N > 1: frame k's bands travel to rank 0 while frame k+1 is rendered (dist.FramePipeline); every frame is
     # assembled on rank 0 inside the timed region
-    pipe = rtdist.FramePipeline(W, H, D, rank, world_size) if distributed else None
+    # ... and a rank has several frames of the sequence in flight, one per stream: a share of a frame ends on the critical path of
+    # its deepest pixels with most of the GPU idle.  One rank (the headline): one frame after the other.
+    in_flight = 1 if not distributed else (args.frames_in_flight if args.frames_in_flight > 0 else (1 if world_size == 1 else (2 if world_size < 8 else 4)))
+    pipe = rtdist.FramePipeline(W, H, D, rank, world_size, in_flight=in_flight) if distributed else None
     step_index = [0]
 
     def step(ev0=None, ev1=None):
-        target = pipe.band(step_index[0]) if distributed else band
-        if ev0 is not None:
-            ev0.record()
-        rt.render_whitted(scene, camera, frame, out=target, ray_count=count)
-        if ev1 is not None:
-            ev1.record()
-        if distributed:
-            prev = pipe.submit(step_index[0])
-            step_index[0] += 1
-            return prev
-        return band
+        if not distributed:
+            if ev0 is not None:
+                ev0.record()
+            rt.render_whitted(scene, camera, frame, out=band, ray_count=count)
+            if ev1 is not None:
+                ev1.record()
+            return band
+        k = step_index[0]
+        step_index[0] += 1
+        with pipe.stream(k):
+            target = pipe.band(k)
+            if ev0 is not None:
+                ev0.record()
+            rt.render_whitted(scene, camera, frame, out=target, ray_count=count)
+            if ev1 is not None:
+                ev1.record()
+            return pipe.submit(k)
 
     full = None
     for _ in range(args.warmup):
@@ -533,7 +545,8 @@ def main() -> int:
                 "workload": f"configs[2]/[1]: dodecahedron.obj scene (the reference's single scene: 64 triangles, 4 spheres, "
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
-                "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame's rendering" if distributed else ""),
+                "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frames' rendering" if distributed else ""),
+                "frames_in_flight": in_flight,
                 "kernel_variant": "persistent-wavefront" if variant & 16 else ("per-pixel, LDS-staged triangles" if variant & 1 else "per-pixel, scalar triangle fetches"),
             },
             "casts_per_frame": casts_per_frame,
@@ -548,7 +561,7 @@ def main() -> int:
                 "executed_valu": executed,
                 "kernel": "rt::pwf_kernel (the persistent render kernel: one launch per frame; the no-op fallback launch behind it is in call_ms_avg)" if variant & 16
                           else "rt::whitted_kernel<8, %s>" % ("true" if variant & 1 else "false"),
-                "kernel_ms_avg": round(kernel_ms_max, 4),
+                "kernel_ms_avg": round(kernel_ms_max, 4),  # (with frames_in_flight > 1 the launches overlap: each lasts longer than a step)
                 "call_ms_avg": round(call_ms, 4),
                 "flop_per_cast": flop_per_cast,
                 "casts_per_launch": casts_this_rank,
@@ -570,7 +583,7 @@ def main() -> int:
     # second stream (its own workspace) while frame k drains.  A frame (and even more a 1/N share) ends with the critical path
     # of its deepest pixels while most of the GPU idles; independent frames fill that.  Same pixels.
     pipelined = None
-    if not args.no_pipelined:
+    if not args.no_pipelined and in_flight == 1:  # (with several frames in flight the headline already is this)
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         bands2 = [torch.empty_like(band), torch.empty_like(band)]
         count2 = torch.zeros(1, dtype=torch.int64, device="cuda")

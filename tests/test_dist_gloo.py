@@ -65,7 +65,7 @@ def test_sharded_frame_equals_single_process(tmp_path, world, w, h):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def _pipeline_worker(rank, world, port, w, h, depths, out_path):
+def _pipeline_worker(rank, world, port, w, h, depths, out_path, in_flight=1, finish_after=None):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -78,24 +78,49 @@ def _pipeline_worker(rank, world, port, w, h, depths, out_path):
     wd = rt.reference_world()
     cam = rt.reference_camera()
     # frames differ (one depth each) so that a mixed-up buffer would show
-    pipe = rtdist.FramePipeline(w, h, max(depths), rank, world, device="cpu")
-    frames = []
+    pipe = rtdist.FramePipeline(w, h, max(depths), rank, world, device="cpu", in_flight=in_flight)
+    frames = []  # in the order rank 0 is handed them
     for k, depth in enumerate(depths):
-        band = pipe.band(k)
-        fr = rtdist.shard_frame(w, h, depth, rank, world)
-        img, _ = _oracle.render_whitted(wd.desc(), cam, fr, threads=2)
-        band.copy_(torch.from_numpy(img))
-        prev = pipe.submit(k)
-        if k >= 1 and rank == 0:
+        with pipe.stream(k):
+            band = pipe.band(k)
+            fr = rtdist.shard_frame(w, h, depth, rank, world)
+            img, _ = _oracle.render_whitted(wd.desc(), cam, fr, threads=2)
+            band.copy_(torch.from_numpy(img))
+            prev = pipe.submit(k)
+        if prev is not None:
+            assert rank == 0
             frames.append(prev.numpy().copy())
-        else:
-            assert k == 0 or prev is None or rank == 0
-    last = pipe.finish()
+        if finish_after == k:  # bench.py's finish() after its warm-up: the frames so far, and none of them again afterwards
+            rest = []
+            pipe.finish(into=rest)
+            frames += [f.numpy().copy() for f in rest if f is not None]
+    rest = []
+    last = pipe.finish(into=rest)
+    frames += [f.numpy().copy() for f in rest if f is not None]
     if rank == 0:
-        frames.append(last.numpy().copy())
+        assert last is not None and np.array_equal(last.numpy(), frames[-1])
         np.save(out_path, np.stack(frames))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("in_flight,finish_after", [(2, None), (2, 2), (3, 1)])
+def test_frames_in_flight_deliver_every_frame_once_and_in_order(tmp_path, in_flight, finish_after):
+    """dist.FramePipeline(in_flight=S) — what bench.py uses for N > 1: 2 S band buffers, frame k - S handed back by submit(k), a
+    finish() in the middle (after the warm-up) and at the end; rank 0 must get every frame exactly once, complete and in order."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import homework_18_graphics_raytracer_amd as rt
+    import _oracle
+
+    world, w, h = 2, 40, 30
+    depths = [0, 1, 2, 3, 1, 0, 2]
+    out = tmp_path / "frames.npy"
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), w, h, depths, str(out), in_flight, finish_after), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape[0] == len(depths)
+    for k, depth in enumerate(depths):
+        want, _ = _oracle.render_whitted(rt.reference_world().desc(), rt.reference_camera(), rt.Frame.full(w, h, depth))
+        assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"frame {k}"
 
 
 @pytest.mark.parametrize("world,w,h", [(2, 48, 36), (3, 40, 31)])

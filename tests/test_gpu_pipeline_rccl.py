@@ -12,7 +12,8 @@ from homework_18_graphics_raytracer_amd import dist as rtdist
 pytestmark = pytest.mark.gpu
 
 
-def test_pipelined_gather_over_rccl_single_rank():
+@pytest.mark.parametrize("in_flight", [1, 2, 4])
+def test_pipelined_gather_over_rccl_single_rank(in_flight):
     import torch
     import torch.distributed as dist
 
@@ -26,16 +27,20 @@ def test_pipelined_gather_over_rccl_single_rank():
         world = rt.reference_world(); cam = rt.reference_camera(); scene = rt.Scene(world)
         w, h = 320, 203
         depths = [0, 2, 5, 1, 3, 8]
-        pipe = rtdist.FramePipeline(w, h, max(depths), 0, 1)
+        pipe = rtdist.FramePipeline(w, h, max(depths), 0, 1, in_flight=in_flight)  # frame k on stream k % in_flight
         got = []
         for k, depth in enumerate(depths):
-            band = pipe.band(k)
-            rt.render_whitted(scene, cam, rt.Frame.full(w, h, depth), out=band)
-            prev = pipe.submit(k)
-            if k >= 1:
-                got.append(prev.clone())
-        got.append(pipe.finish().clone())
+            with pipe.stream(k):
+                band = pipe.band(k)
+                rt.render_whitted(scene, cam, rt.Frame.full(w, h, depth), out=band)
+                prev = pipe.submit(k)
+                if prev is not None:
+                    got.append(prev.clone())
+        rest = []
+        pipe.finish(into=rest)
+        got += [f.clone() for f in rest]
         torch.cuda.synchronize()
+        assert len(got) == len(depths)
         for k, depth in enumerate(depths):
             want = rt.render_whitted(scene, cam, rt.Frame.full(w, h, depth))
             torch.cuda.synchronize()
