@@ -404,6 +404,12 @@ def main() -> int:
     if args.gpus > 1 and world_size == 1:
         return relaunch_under_torchrun(args)  # child process; nothing has touched the GPU yet
 
+    # stdout carries ONE line, the JSON: whatever else writes to file descriptor 1 from here on (RCCL prints its version there when a
+    # process group is made; make's output) goes to stderr instead, and the line is written to the real stdout at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import __graft_entry__
 
     rank = int(os.environ.get("RANK", "0"))
@@ -660,7 +666,8 @@ def main() -> int:
         if scatter is not None:
             scatter["parity"] = "tests/test_gpu_distributed_parity.py::test_scatter_job_of_configs4_equals_the_oracle (the whole job: samples, flags, generator records, casts)"
             line["scatter_pass"] = scatter
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
         # a fast frame that differs from the reference algorithm's is not a result: fail loudly
         if line.get("cpu_baseline", {}).get("gpu_frame_bit_identical_to_cpu") is False:
             sys.stderr.write("bench.py: the GPU frame differs from the CPU oracle's\n")
