@@ -29,7 +29,7 @@ extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = stati
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
     "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
     "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
-    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_BFS_WALK_TRIANGLES"};
+    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_BFS_WALK_TRIANGLES", "RT_AMD_DIAG_BFS_CAP"};
 static std::atomic<int> g_opt_set[rt::OPT_COUNT];
 static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
 static std::once_flag g_opt_once;
@@ -465,6 +465,11 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
                 pw.bfs_scratch = ws.d_bfs;
                 pw.bfs_items_cap = RT_BFS_ITEMS_CAP;
                 pw.bfs_jobs_cap = RT_BFS_JOBS_CAP;
+                const long long cap = rt::option(rt::OPT_DIAG_BFS_CAP, 0); /* test hook: shorter lists (the memory is the same) */
+                if (cap > 0) {
+                    pw.bfs_items_cap = (uint32_t)std::min<long long>(cap, RT_BFS_ITEMS_CAP);
+                    pw.bfs_jobs_cap = (uint32_t)std::min<long long>(cap, RT_BFS_JOBS_CAP);
+                }
             }
             if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
             pw.tile_order = g_diag_tile_order.load();

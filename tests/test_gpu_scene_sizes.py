@@ -126,3 +126,19 @@ def test_scenes_above_the_switch_take_the_breadth_first_walk(tmp_path, spherize)
             finally:
                 _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
             assert _same(got, want) and casts == wcasts, (variant, frame.width)
+
+
+@pytest.mark.parametrize("cap", [8, 96, 700])
+def test_breadth_first_walk_with_lists_that_overflow(tmp_path, cap):
+    """A wave-cast whose record lists overflow (RT_BFS_ITEMS_CAP / RT_BFS_JOBS_CAP records: no scene of the sweep gets there) takes
+    the wave-uniform walk instead — here the lists are cut to a few records (RT_AMD_DIAG_BFS_CAP), so that some wave-casts overflow at
+    level 0, some in a later level, some in the jobs, and the rest walk breadth-first: the same pixels and cast counts either way."""
+    world, cam = _scene(tmp_path, 3, True)
+    desc = world.desc()
+    with rt.options(RT_AMD_BFS_WALK_TRIANGLES=1, RT_AMD_DIAG_BFS_CAP=cap):
+        scene = rt.Scene(world)
+        flat = rt.Scene(_scenes.clustered_world(3, n_boxes=3))
+        for sc, d, camera, frame in [(scene, desc, cam, rt.Frame.full(96, 72, 5)), (flat, _scenes.clustered_world(3, n_boxes=3).desc(), _scenes.camera(3), rt.Frame.full(80, 60, 4))]:
+            want, wcasts = _oracle.render_whitted(d, camera, frame)
+            got, casts = rt.render_whitted_numpy(sc, camera, frame)
+            assert _same(got, want) and casts == wcasts
