@@ -221,10 +221,13 @@ int rt_render_distributed(const rt_scene *scene, const rt_camera *camera, const 
     dp.pixel_order = nullptr;
     dp.pixel_cost = nullptr;
     dp.own_first_chunk = 0u;
+    dp.bfs_scratch = nullptr;
+    dp.bfs_items_cap = dp.bfs_jobs_cap = 0u;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     uint32_t dist_waves = scene->resident_waves;
     int split = g_dist_split.load();
     if (split < 0) split = rt::option(rt::OPT_DIST_SPLIT, RT_DIST_SPLIT_DEFAULT) != 0 ? 1 : 0;
+    if (scene->ks.bfs_walk != 0u) split = 0; /* a scene beyond the caches: the one-kernel organisation has the breadth-first walk (below) */
     const size_t n_pixels = (size_t)kf.cols * kf.rows;
     if (n_pixels == 0 || n_epochs == 0) return RT_OK;
     /* the switches (rt_kernels.h Option; rt_set_option or, once per process, the environment) */
@@ -384,6 +387,28 @@ one_kernel:
             Workspace &ws = mut->workspaces[stream];
             RT_HIP(ensure_counters(ws));
             dp.work_queue = ws.d_counters;
+            if (scene->ks.bfs_walk != 0u) { /* the breadth-first walk's lists, one set per wave of the grid (shared with the Whitted path of this stream) */
+                const uint32_t waves = rt::dist_bfs_waves(rng->compute_units);
+                const size_t words = (size_t)waves * rt::pwf_bfs_scratch_words_per_wave();
+                if (ws.bfs_words < words) {
+                    if (ws.d_bfs) (void)hipFree(ws.d_bfs);
+                    ws.d_bfs = nullptr;
+                    ws.bfs_words = 0;
+                    if (hipMalloc(reinterpret_cast<void **>(&ws.d_bfs), words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); ws.d_bfs = nullptr; }
+                    else ws.bfs_words = words;
+                }
+                if (ws.d_bfs != nullptr) { /* (no room: the wave-uniform walk renders the same samples) */
+                    dp.bfs_scratch = ws.d_bfs;
+                    dp.bfs_items_cap = RT_BFS_ITEMS_CAP;
+                    dp.bfs_jobs_cap = RT_BFS_JOBS_CAP;
+                    const long long cap = rt::option(rt::OPT_DIAG_BFS_CAP, 0);
+                    if (cap > 0) {
+                        dp.bfs_items_cap = (uint32_t)std::min<long long>(cap, RT_BFS_ITEMS_CAP);
+                        dp.bfs_jobs_cap = (uint32_t)std::min<long long>(cap, RT_BFS_JOBS_CAP);
+                    }
+                    if (dist_waves > waves) dist_waves = waves;
+                }
+            }
         }
     }
     hipError_t e = hipSuccess;

@@ -454,10 +454,25 @@ struct DFrame {
 #ifndef RT_DIST_MIN_WAVES
 #define RT_DIST_MIN_WAVES 3 /* waves per SIMD the register allocation aims for (profiles/README.md) */
 #endif
-template <int MAXD>
-__global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
+/* BFS: the casts as a breadth-first walk of the node tree (rt_cast.h cast_bfs), for scenes beyond the caches (KernelScene::bfs_walk):
+ * 256 VGPRs, two waves per SIMD, 5 KB of LDS and a set of record lists per wave */
+#define RT_DIST_BFS_WAVES 2
+template <int MAXD, bool BFS = false>
+__global__ __launch_bounds__(64, BFS ? RT_DIST_BFS_WAVES : RT_DIST_MIN_WAVES) void distributed_kernel(const KernelScene sc, const KernelFrame fr, const DistParams dp) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    BfsLds *bfs_lds = nullptr;
+    BfsScratch bfs_ws = {nullptr, nullptr, nullptr, 0u, 0u};
+    if constexpr (BFS) {
+        __shared__ BfsLds bfs_lds_one;
+        bfs_lds = &bfs_lds_one;
+        uint2 *const mine = reinterpret_cast<uint2 *>(dp.bfs_scratch) + (size_t)wave * (2u * (size_t)dp.bfs_items_cap + dp.bfs_jobs_cap);
+        bfs_ws.items_a = mine;
+        bfs_ws.items_b = mine + dp.bfs_items_cap;
+        bfs_ws.jobs = mine + 2u * (size_t)dp.bfs_items_cap;
+        bfs_ws.items_cap = dp.bfs_items_cap;
+        bfs_ws.jobs_cap = dp.bfs_jobs_cap;
+    }
     const uint32_t total_slots = fr.cols * fr.rows;
     const uint32_t band_slots = fr.cols << 3;
     /* Persistent lanes: a lane takes a pixel, runs ALL of this call's epochs for it (the pixel's random stream
@@ -575,7 +590,10 @@ __global__ __launch_bounds__(64, RT_DIST_MIN_WAVES) void distributed_kernel(cons
         cr.t = 0.0f;
         cr.bf = 0u;
         cr.a0 = cr.a1 = cr.a2 = 0.0f;
-        if (phase != DP_DONE) {
+        if constexpr (BFS) {
+            cr = cast_bfs(sc, req, phase != DP_DONE, bfs_lds, bfs_ws); /* all lanes: those without a ray help */
+            if (phase != DP_DONE) casts += 1u;
+        } else if (phase != DP_DONE) {
             cr = cast_asm(sc, req);
             casts += 1u;
         }
@@ -839,6 +857,11 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
     uint32_t waves = (total + 63u) / 64u;
     if (waves == 0u) return hipSuccess;
     if (dp.work_queue != nullptr && waves > resident_waves) waves = resident_waves; /* persistent lanes: fill the chip once */
+    if (sc.bfs_walk != 0u && dp.bfs_scratch != nullptr && dp.work_queue != nullptr) { /* (the caller sized resident_waves by dist_bfs_waves) */
+        if (fr.max_depth <= 8) hipLaunchKernelGGL((distributed_kernel<9, true>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+        else hipLaunchKernelGGL((distributed_kernel<RT_MAX_DEPTH + 1, true>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
+        return hipGetLastError();
+    }
     if (fr.max_depth <= 8) {
         hipLaunchKernelGGL((distributed_kernel<9>), dim3(waves), dim3(64), 0, stream, sc, fr, dp);
     } else {
@@ -846,6 +869,7 @@ hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, cons
     }
     return hipGetLastError();
 }
+uint32_t dist_bfs_waves(uint32_t compute_units) { return compute_units * 4u * (uint32_t)RT_DIST_BFS_WAVES; }
 
 
 /* ---- the split pass ----------------------------------------------------------------------------------------------

@@ -183,6 +183,10 @@ struct DistParams {
      * staggered answers are worth more than they cost — waves that start together stay in step and ask memory together: 1 165 ->
      * 1 126 Msamples/s in 8-epoch calls with every wave's first chunk its own (profiles/r03_ab12.txt) */
     uint32_t own_first_chunk;
+    /* scenes with KernelScene::bfs_walk (the one-kernel organisation only): the breadth-first walk's lists, per wave of the grid two
+     * level lists of bfs_items_cap records and a job list of bfs_jobs_cap records, as in PwParams; null: the wave-uniform walk */
+    uint32_t *bfs_scratch;
+    uint32_t bfs_items_cap, bfs_jobs_cap;
 };
 size_t distributed_split_bytes_per_sample(int32_t max_depth);
 #define RT_RNG_STATE_WORDS 516u   /* the oracle's / reference's record: what rt_rng_download returns per pixel */
@@ -192,6 +196,7 @@ hipError_t launch_rng_seed(uint32_t *states, const KernelFrame &fr, hipStream_t 
 hipError_t launch_rng_prepare(uint32_t *states, uint32_t n_pixels, uint32_t *list, uint32_t compute_units, hipStream_t stream);
 hipError_t launch_rng_export(const uint32_t *states, uint32_t n_pixels, uint32_t *out, hipStream_t stream);
 hipError_t launch_distributed(const KernelScene &sc, const KernelFrame &fr, const DistParams &dp, uint32_t resident_waves, hipStream_t stream);
+uint32_t dist_bfs_waves(uint32_t compute_units); /* the grid of launch_distributed, at most, when dp.bfs_scratch is set: one list set per wave */
 /* the split pass, one batch of dp.n_epochs epochs: the chain kernel (all random draws; dp.work_queue zeroed), and — once it has
  * finished — the shade and unwind kernels, which only read what it recorded and never touch the RNG records: the caller may start
  * the look-ahead for the next batch, and the next batch's chain kernel on another workspace, beside them */

@@ -142,3 +142,30 @@ def test_breadth_first_walk_with_lists_that_overflow(tmp_path, cap):
             want, wcasts = _oracle.render_whitted(d, camera, frame)
             got, casts = rt.render_whitted_numpy(sc, camera, frame)
             assert _same(got, want) and casts == wcasts
+
+
+@pytest.mark.parametrize("level,spherize,cap", [(2, True, 0), (2, False, 0), (3, True, 96)])
+def test_stochastic_pass_with_the_breadth_first_walk(tmp_path, level, spherize, cap):
+    """The depth-of-field pass of a scene beyond the caches: rt_render_distributed takes the one-kernel organisation, whose casts are
+    the breadth-first walk (distributed_kernel<.., BFS>) — forced on here for small scenes, once with lists that overflow.  Samples,
+    filter flags, generator records and cast count against the oracle."""
+    import torch
+
+    world, cam = _scene(tmp_path, level, spherize)
+    desc = world.desc()
+    opts = {"RT_AMD_BFS_WALK_TRIANGLES": 1}
+    if cap:
+        opts["RT_AMD_DIAG_BFS_CAP"] = cap
+    with rt.options(**opts):
+        scene = rt.Scene(world)
+        frame = rt.Frame.full(64, 48, 5)
+        rng = rt.Rng(frame)
+        samples = torch.empty((2, frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+        valid = torch.empty((2, frame.rows, frame.cols), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        rt.render_distributed(scene, cam, frame, rng, 2, samples=samples, valid=valid, ray_count=cnt)
+        torch.cuda.synchronize()
+    st = _oracle.rng_init(frame)
+    ws, wv, wcasts = _oracle.render_distributed(desc, cam, frame, st, 2)
+    assert _same(samples.cpu().numpy(), ws) and np.array_equal(valid.cpu().numpy(), wv) and int(cnt.item()) == wcasts
+    assert np.array_equal(rng.download(), st)

@@ -31,6 +31,7 @@ ap.add_argument("--spherize", action="store_true")
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--frames", type=int, default=0, help="timed frames (0: chosen per size)")
 ap.add_argument("--no-parity", action="store_true")
+ap.add_argument("--dof-epochs", type=int, default=0, help="also time this many epochs of the depth-of-field pass on the timed frame (one call, fresh streams, after a warm call of one epoch)")
 ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("W", "H"), help="timed frame size (default: by scene size, 1920x1080 up to 3000 triangles, 960x540 up to 40000, 480x270 above)")
 ap.add_argument("--out", default=None)
 ap.add_argument("--tile-order", default="default", choices=["default", "image"], help="image: the wavefront kernel takes its 8x8 tiles in image order (rt_diag_set_tile_order) instead of scattered by the golden-section stride: all workgroups then work in one region of the image at a time")
@@ -124,6 +125,22 @@ with tempfile.TemporaryDirectory() as tmp:
                    "width": W, "height": H, "depth": a.depth, "frames": n, "ms_per_frame": round(ms, 4), "casts_per_frame": casts,
                    "Mrays_per_s": round(casts / ms / 1e3, 2), "Gtri_tests_per_s": round(casts * T / ms / 1e6, 2),
                    "parity_vs_oracle_small_frame": parity, "tile_order": a.tile_order, "bfs_walk_from_triangles": a.bfs_walk}
+            if a.dof_epochs and v == a.variants[0]:
+                acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+                dcnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+                warm = rt.Rng(frame)
+                rt.render_distributed(scene, file_cam, frame, warm, 1, accum=acc)
+                torch.cuda.synchronize()
+                warm.close()
+                rng = rt.Rng(frame)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rt.render_distributed(scene, file_cam, frame, rng, a.dof_epochs, accum=acc, ray_count=dcnt)
+                torch.cuda.synchronize()
+                dms = (time.perf_counter() - t0) * 1e3 / a.dof_epochs
+                rng.close()
+                rec.update({"dof_epochs": a.dof_epochs, "dof_ms_per_epoch": round(dms, 3), "dof_Msamples_per_s": round(W * H / dms / 1e3, 3),
+                            "dof_Mrays_per_s": round(int(dcnt.item()) / a.dof_epochs / dms / 1e3, 2)})
             lines.append(rec)
             print(json.dumps(rec), flush=True)
         _capi.check(lib.rt_set_variant(_capi.DEFAULT_VARIANT))
