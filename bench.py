@@ -47,8 +47,8 @@ def parse_args():
     p.add_argument("--no-stochastic", action="store_true", help="skip the depth-of-field pass (configs[3]: 64 samples per pixel, sharded like the frame), measured after the headline's timed region")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = all cores)")
     p.add_argument("--frames-in-flight", type=int, default=0,
-                   help="N > 1 only: frames a rank renders at once, one per stream (dist.FramePipeline in_flight); 0 = 2 for fewer than 8 ranks, 4 from 8 "
-                        "(a 1/8 share of the frame leaves the GPU mostly idle: profiles/r04_frames_in_flight.txt); 1 = one after the other")
+                   help="N > 1 only: frames a rank renders at once, one per stream (dist.FramePipeline in_flight); 0 = 4, each launch on a quarter of the "
+                        "device (a share of the frame leaves the GPU mostly idle: profiles/r04_frames_in_flight.txt); 1 = one after the other")
     p.add_argument("--no-extras", action="store_true", help="skip the sharded_finish, share_timing and large_scene objects (after everything else)")
     return p.parse_args()
 
@@ -454,8 +454,12 @@ def main() -> int:
     # assembled on rank 0 inside the timed region
     # ... and a rank has several frames of the sequence in flight, one per stream: a share of a frame ends on the critical path of
     # its deepest pixels with most of the GPU idle.  One rank (the headline): one frame after the other.
-    in_flight = 1 if not distributed else (args.frames_in_flight if args.frames_in_flight > 0 else (1 if world_size == 1 else (2 if world_size < 8 else 4)))
+    in_flight = 1 if not distributed else (args.frames_in_flight if args.frames_in_flight > 0 else (1 if world_size == 1 else 4))
     pipe = rtdist.FramePipeline(W, H, D, rank, world_size, in_flight=in_flight) if distributed else None
+    # from three in flight each launch takes its part of the device's workgroups, so that the frames run side by side instead of one
+    # behind the other's tail (RT_AMD_WF_SHARE; profiles/r04_frames_in_flight.txt: a 1/8 share 0.168 -> 0.153 ms per frame with four,
+    # and the larger shares, which four whole-device launches in flight would slow down, gain too)
+    device_share = in_flight if in_flight >= 3 else 1
     step_index = [0]
 
     def step(ev0=None, ev1=None):
@@ -477,6 +481,8 @@ def main() -> int:
                 ev1.record()
             return pipe.submit(k)
 
+    if device_share > 1:
+        rt.set_option("RT_AMD_WF_SHARE", device_share)
     full = None
     for _ in range(args.warmup):
         full = step()
@@ -499,6 +505,8 @@ def main() -> int:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if device_share > 1:
+        rt.set_option("RT_AMD_WF_SHARE", None)  # the other passes of this run use the whole device
 
     call_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, args.steps)  # whole call: probe + render kernels
     ksum, kn = C.c_double(0.0), C.c_uint(0)
@@ -552,7 +560,7 @@ def main() -> int:
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
                 "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frames' rendering" if distributed else ""),
-                "frames_in_flight": in_flight,
+                "frames_in_flight": in_flight, "device_share_per_launch": f"1/{device_share}",
                 "kernel_variant": "persistent-wavefront" if variant & 16 else ("per-pixel, LDS-staged triangles" if variant & 1 else "per-pixel, scalar triangle fetches"),
             },
             "casts_per_frame": casts_per_frame,

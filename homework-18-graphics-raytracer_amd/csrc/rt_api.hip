@@ -29,7 +29,7 @@ extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = stati
 static const char *const OPT_NAMES[rt::OPT_COUNT] = {
     "RT_AMD_RNG_LOOKAHEAD", "RT_AMD_RNG_OVERLAP", "RT_AMD_DIST_PIPELINE", "RT_AMD_DIST_BY_COST", "RT_AMD_DIST_OWN_FIRST", "RT_AMD_DIST_PREP_FIRST",
     "RT_AMD_DIST_WS_MB", "RT_AMD_DIAG_WS_REFUSE", "RT_AMD_DIST_STATIC", "RT_AMD_DIST_CHAIN_WAVES", "RT_AMD_SHADE_TILE", "RT_AMD_SHADE_SORT",
-    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_BFS_WALK_TRIANGLES", "RT_AMD_DIAG_BFS_CAP"};
+    "RT_AMD_MULTI_FORCE_STAGE", "RT_AMD_DIST_SPLIT", "RT_AMD_BFS_WALK_TRIANGLES", "RT_AMD_WF_SHARE", "RT_AMD_DIAG_BFS_CAP"};
 static std::atomic<int> g_opt_set[rt::OPT_COUNT];
 static std::atomic<long long> g_opt_val[rt::OPT_COUNT];
 static std::once_flag g_opt_once;
@@ -409,6 +409,11 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             const uint64_t pixels = (uint64_t)kf.cols * kf.rows;
             uint64_t groups = (pixels + 63u) / 64u; /* a workgroup fetches one to eight tiles at a time */
             if (groups > scene->pwf_workgroups) groups = scene->pwf_workgroups;
+            {   /* frames in flight on several streams: each launch takes a part of the device, so that they run side by side */
+                const long long share = rt::option(rt::OPT_WF_SHARE, 1);
+                const uint64_t cap = share > 1 ? ((uint64_t)scene->pwf_workgroups + (uint64_t)share - 1u) / (uint64_t)share : (uint64_t)scene->pwf_workgroups;
+                if (groups > cap) groups = cap;
+            }
             if (groups < 1) groups = 1;
             const uint64_t max_pixels = (ring_max - 1024u) * groups / (uint64_t)wf_budget;
             pw_band_rows = kf.rows;

@@ -102,6 +102,7 @@ enum Option : int {
     OPT_MULTI_FORCE_STAGE, /* test hook: rt_multi_* stage every band as if it lived on another device */
     OPT_DIST_SPLIT,        /* 0: the one-kernel organisation (rt_set_distributed_split has the last word) */
     OPT_BFS_WALK_TRIANGLES, /* scenes of at least this many triangles are walked breadth-first by the wavefront kernel (0: never); read by rt_scene_create */
+    OPT_WF_SHARE,           /* n > 1: a launch of the persistent wavefront kernel takes 1/n of the workgroups the device holds — a caller with n frames in flight on n streams runs them side by side instead of one behind the other's tail */
     OPT_DIAG_BFS_CAP,       /* test hook: that walk's record lists hold this many records at most (default: RT_BFS_ITEMS_CAP / RT_BFS_JOBS_CAP): a wave-cast that needs more takes the wave-uniform walk */
     OPT_COUNT
 };

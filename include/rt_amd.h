@@ -328,7 +328,7 @@ int rt_accumulator_resolve_device(const float *d_sum, const float *d_weight, siz
  * named like the environment variable that seeds it — RT_AMD_DIST_PIPELINE, RT_AMD_DIST_WS_MB, RT_AMD_RNG_LOOKAHEAD,
  * RT_AMD_RNG_OVERLAP, RT_AMD_DIST_BY_COST, RT_AMD_DIST_OWN_FIRST, RT_AMD_DIST_PREP_FIRST, RT_AMD_DIST_SPLIT, RT_AMD_DIST_STATIC,
  * RT_AMD_DIST_CHAIN_WAVES, RT_AMD_SHADE_TILE, RT_AMD_SHADE_SORT, RT_AMD_DIAG_WS_REFUSE,
- * RT_AMD_MULTI_FORCE_STAGE, RT_AMD_BFS_WALK_TRIANGLES (read by rt_scene_create), RT_AMD_DIAG_BFS_CAP (INTEGRATION.md says what each does).  The environment is read ONCE per process, at the first use;
+ * RT_AMD_MULTI_FORCE_STAGE, RT_AMD_BFS_WALK_TRIANGLES (read by rt_scene_create), RT_AMD_WF_SHARE, RT_AMD_DIAG_BFS_CAP (INTEGRATION.md says what each does).  The environment is read ONCE per process, at the first use;
  * after that only this call changes a switch: value = decimal integer, NULL or "" = unset (the library's own choice).  Render
  * calls read the switches without locks: set them between calls, not during one. */
 int rt_set_option(const char *name, const char *value);

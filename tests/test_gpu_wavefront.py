@@ -193,6 +193,30 @@ def test_two_streams_render_concurrently_with_their_own_workspaces(ref):
             assert torch.equal(outs[k].view(torch.int32), want[k].view(torch.int32))
 
 
+@pytest.mark.parametrize("share", [2, 4, 1000])
+def test_frames_in_flight_side_by_side_on_parts_of_the_device(ref, share):
+    """RT_AMD_WF_SHARE = n: a launch of the persistent kernel takes 1/n of the workgroups the device holds (one workgroup at the
+    least), so that n frames in flight on n streams run side by side (dist.FramePipeline(in_flight=n), bench.py for N > 1).  The same
+    pixels and cast counts as the oracle's, whatever the share."""
+    import torch
+
+    world, cam, scene = ref
+    frames = [rt.Frame.full(320, 240, 8), rt.Frame.rows_of_rank(640, 360, 6, 0, 4)]
+    want = [_oracle.render_whitted(world.desc(), cam, f) for f in frames]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    with rt.options(RT_AMD_WF_SHARE=share):
+        for k, f in enumerate(frames):
+            outs = [torch.zeros((f.rows, f.cols, 3), dtype=torch.float32, device="cuda") for _ in streams]
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            for rep in range(2):
+                for o, st in zip(outs, streams):
+                    rt.render_whitted(scene, cam, f, out=o, ray_count=cnt, stream=st)
+            torch.cuda.synchronize()
+            for o in outs:
+                assert np.array_equal(o.cpu().numpy().view(np.uint32), want[k][0].view(np.uint32))
+            assert int(cnt.item()) == 2 * len(streams) * want[k][1]
+
+
 def test_two_host_threads_render_concurrently_with_profiling_on(ref):
     """rt_render_whitted from two HOST threads, each on its own stream, with the profiling hooks enabled: the settings
     are atomics, the workspaces are created under the scene's lock and a call's event pair is thread-local, so both

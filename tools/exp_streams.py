@@ -22,6 +22,8 @@ ap.add_argument("--frames", type=int, default=240)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--split-device", action="store_true", help="RT_AMD_WF_SHARE = S: each launch takes 1/S of the workgroups the device holds — the S kernels in flight side by side instead of one behind the tail of the other")
+ap.add_argument("--graph", action="store_true", help="each stream's render call captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed: what the host pays per frame is one graph launch")
 a = ap.parse_args()
 scene = rt.Scene(rt.reference_world())
 cam = rt.reference_camera()
@@ -30,12 +32,28 @@ for world in a.worlds:
     base = None
     for S in a.streams:
         streams = [torch.cuda.Stream() for _ in range(S)]
+        rt.set_option("RT_AMD_WF_SHARE", S if a.split_device and S > 1 else None)
         outs = [torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda") for _ in range(S)]
+
+        graphs = None
+        if a.graph:
+            graphs = []
+            for i in range(S):
+                with torch.cuda.stream(streams[i]):
+                    rt.render_whitted(scene, cam, frame, out=outs[i])  # the stream's workspace exists before the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=streams[i]):
+                    rt.render_whitted(scene, cam, frame, out=outs[i])
+                graphs.append(g)
 
         def run(n):
             for k in range(n):
                 with torch.cuda.stream(streams[k % S]):
-                    rt.render_whitted(scene, cam, frame, out=outs[k % S])
+                    if graphs is not None:
+                        graphs[k % S].replay()
+                    else:
+                        rt.render_whitted(scene, cam, frame, out=outs[k % S])
             torch.cuda.synchronize()
 
         run(4 * S)
@@ -45,4 +63,4 @@ for world in a.worlds:
         if S == a.streams[0]:
             base = ms
         same = all(torch.equal(outs[0], o) for o in outs[1:])
-        print(f"share 1/{world}: {S} frame(s) in flight: {ms:.4f} ms per frame ({base / ms:.2f}x one in flight), frames identical: {same}", flush=True)
+        print(f"share 1/{world}{', graphs' if a.graph else ''}{', device split' if a.split_device and S > 1 else ''}: {S} frame(s) in flight: {ms:.4f} ms per frame ({base / ms:.2f}x one in flight), frames identical: {same}", flush=True)
