@@ -313,7 +313,7 @@ def share_timing(scene, camera, width, height, depth, steps):
 def large_scene(camera, width, height, depth, levels=6):
     """the same literal scene around the dodecahedron tessellated 4^levels ways (147 484 triangles at 6: 28 MB of
     records, beyond every cache), the headline's frame.  rt_scene_create gives such a scene the breadth-first walk of the node tree
-    (rt_cast.h cast_bfs; bit-identical to the oracle at every size: tests/test_gpu_scene_sizes.py, tools/scene_sweep.py).  Timed like
+    (rt_cast_bfs.h cast_bfs; bit-identical to the oracle at every size: tests/test_gpu_scene_sizes.py, tools/scene_sweep.py).  Timed like
     the headline, three frames after a warm one; 'algorithmic' triangle tests = casts x triangles, what the reference's loop runs."""
     import subprocess
     import tempfile

@@ -315,7 +315,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out_scene) {
     sc->ks.bfs_nodes = reinterpret_cast<const rt::DevSegment *>(base + off_bfs_nodes);
     sc->ks.bfs_soa = reinterpret_cast<const float4 *>(base + off_bfs_soa);
     sc->ks.bfs_top = bfs_top;
-    {   /* a scene this large is walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs): node ids must fit 26 bits */
+    {   /* a scene this large is walked breadth-first by the wavefront kernel (rt_cast_bfs.h cast_bfs): node ids must fit 26 bits */
         const long long at = rt::option(rt::OPT_BFS_WALK_TRIANGLES, RT_BFS_WALK_TRIANGLES_DEFAULT);
         sc->ks.bfs_walk = at > 0 && (long long)desc->n_triangles >= at && segments.size() < (1u << 26) ? 1u : 0u;
     }

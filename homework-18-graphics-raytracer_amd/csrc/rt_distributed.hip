@@ -454,7 +454,7 @@ struct DFrame {
 #ifndef RT_DIST_MIN_WAVES
 #define RT_DIST_MIN_WAVES 3 /* waves per SIMD the register allocation aims for (profiles/README.md) */
 #endif
-/* BFS: the casts as a breadth-first walk of the node tree (rt_cast.h cast_bfs), for scenes beyond the caches (KernelScene::bfs_walk):
+/* BFS: the casts as a breadth-first walk of the node tree (rt_cast_bfs.h cast_bfs), for scenes beyond the caches (KernelScene::bfs_walk):
  * 256 VGPRs, two waves per SIMD, 5 KB of LDS and a set of record lists per wave */
 #define RT_DIST_BFS_WAVES 2
 template <int MAXD, bool BFS = false>

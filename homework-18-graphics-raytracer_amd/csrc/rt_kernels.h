@@ -52,7 +52,7 @@ struct KernelScene {
     const LightAux *light_aux;  /* per light: the cosine of a spot light's spread with its margins (rt_shade.h light_asks) */
     /* the node tree once more, in level order: bfs_nodes[0 .. bfs_top) are the top-level nodes, and an INNER node's record names its
      * children as bfs_nodes[first .. first + skip_to) (a leaf's first / count are its triangles, as in `segments`) — what a
-     * breadth-first walk needs (rt_cast.h cast_bfs).  bfs_walk != 0: the scene is large enough for the kernels that have that walk to
+     * breadth-first walk needs (rt_cast_bfs.h cast_bfs).  bfs_walk != 0: the scene is large enough for the kernels that have that walk to
      * use it (rt_scene_create) */
     const DevSegment *bfs_nodes;
     /* the same once more as arrays of 16-byte pieces, one after the other: n_segments x (first, count, n_normals, r2_hi), n_segments x

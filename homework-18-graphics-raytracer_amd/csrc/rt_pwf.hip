@@ -220,7 +220,7 @@ __device__ unsigned long long pa_phase_stats[32];
 /* the frame description travels through memory (pp.frame, written by pwf_init_kernel): it is read once per tile, and as a
  * by-value argument its 25 dwords would sit in SGPRs across the intersection loop, which needs those itself */
 /* PACKED: the arena queues' page counters two to a word (rt_pwf_common.h): frames of several megapixels.
- * BFS: the intersection loop as a breadth-first walk of the node tree, ray by ray (rt_cast.h cast_bfs): scenes beyond the caches
+ * BFS: the intersection loop as a breadth-first walk of the node tree, ray by ray (rt_cast_bfs.h cast_bfs): scenes beyond the caches
  * (KernelScene::bfs_walk); 20 KB more LDS per workgroup for the waves' ray tables */
 template <bool PACKED, bool BFS = false>
 __global__ __launch_bounds__(PA_THREADS, BFS ? 2 : PA_MIN_WAVES) void pwf_kernel(const KernelScene sc, const PwParams pp, float *__restrict__ out) {

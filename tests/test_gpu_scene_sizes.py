@@ -87,7 +87,7 @@ def test_rt_render_renders_a_scene_file(tmp_path):
 
 @pytest.mark.parametrize("level,spherize", [(0, False), (2, True), (3, False)])
 def test_breadth_first_walk_equals_the_oracle(tmp_path, level, spherize):
-    """rt_cast.h cast_bfs — the node tree walked breadth-first, ray by ray: records of (ray, up to 16 nodes) level by level, jobs of
+    """rt_cast_bfs.h cast_bfs — the node tree walked breadth-first, ray by ray: records of (ray, up to 16 nodes) level by level, jobs of
     (ray, up to 16 triangles), band jobs for leaves only kept because the ray is nearly parallel to a plane, the nearest hit as a
     minimum over (distance, ~index) keys — the form the persistent wavefront kernel takes for scenes beyond the caches
     (rt_scene_create: RT_AMD_BFS_WALK_TRIANGLES), forced on here for scenes of every size: the reference scene itself, a

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: what the breadth-first walk (rt_cast.h cast_bfs) does per wave-cast on a tessellated scene (build: make -C csrc variant
+"""Diagnostic: what the breadth-first walk (rt_cast_bfs.h cast_bfs) does per wave-cast on a tessellated scene (build: make -C csrc variant
 TAG=bfsdiag EXTRA=-DRT_DIAG_BFS).
 
     python tools/diag_bfs.py [--levels 4 5 6] [--spherize]

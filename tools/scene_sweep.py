@@ -35,7 +35,7 @@ ap.add_argument("--dof-epochs", type=int, default=0, help="also time this many e
 ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("W", "H"), help="timed frame size (default: by scene size, 1920x1080 up to 3000 triangles, 960x540 up to 40000, 480x270 above)")
 ap.add_argument("--out", default=None)
 ap.add_argument("--tile-order", default="default", choices=["default", "image"], help="image: the wavefront kernel takes its 8x8 tiles in image order (rt_diag_set_tile_order) instead of scattered by the golden-section stride: all workgroups then work in one region of the image at a time")
-ap.add_argument("--bfs-walk", type=int, default=None, help="RT_AMD_BFS_WALK_TRIANGLES for the scenes of this run: scenes of at least this many triangles are walked breadth-first by the wavefront kernel (rt_cast.h cast_bfs); 0 never, 1 always; default: the library's")
+ap.add_argument("--bfs-walk", type=int, default=None, help="RT_AMD_BFS_WALK_TRIANGLES for the scenes of this run: scenes of at least this many triangles are walked breadth-first by the wavefront kernel (rt_cast_bfs.h cast_bfs); 0 never, 1 always; default: the library's")
 ap.add_argument("--lib", default=None, help="variant tag: use variants/librt_amd_<tag>.so instead of the in-tree library")
 a = ap.parse_args()
 
