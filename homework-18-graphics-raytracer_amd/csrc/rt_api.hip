@@ -15,6 +15,8 @@
 static std::atomic<int> g_wf_nodes_per_pixel{-1};
 static std::atomic<const uint32_t *> g_diag_tile_order{nullptr};
 extern "C" void rt_diag_set_tile_order(const void *device_ptr) { g_diag_tile_order.store(static_cast<const uint32_t *>(device_ptr)); }
+static std::atomic<uint32_t *> g_diag_tile_cost{nullptr};
+extern "C" void rt_diag_set_tile_cost(void *device_ptr) { g_diag_tile_cost.store(static_cast<uint32_t *>(device_ptr)); }
 #ifdef RT_DIAG_TIMELINE
 static unsigned long long *g_diag_timeline = nullptr;
 extern "C" void rt_diag_set_timeline(void *device_ptr) { g_diag_timeline = static_cast<unsigned long long *>(device_ptr); }
@@ -478,6 +480,7 @@ int rt_render_whitted(const rt_scene *scene, const rt_camera *camera, const rt_f
             }
             if (ws.d_pwf == nullptr) variant = RT_VARIANT_SGPR | RT_VARIANT_STATIC; /* no room for the arenas: the per-pixel kernel renders the frame */
             pw.tile_order = g_diag_tile_order.load();
+            pw.tile_cost = g_diag_tile_cost.load();
             static_assert(PW_G_BLOCK_WORDS * sizeof(uint32_t) == 128, "two blocks of global words and the frame description share the 512-byte header");
             static_assert(sizeof(rt::KernelFrame) <= 128, "the frame description must fit its slot of the workspace header");
             pw.frame = reinterpret_cast<const rt::KernelFrame *>(static_cast<unsigned char *>(ws.d_pwf) + 256);

@@ -135,6 +135,7 @@ struct PwParams {
     uint32_t tile_reserve;  /* nodes an arena must have free per primary ray before it takes more tiles */
     uint32_t tile_stride;   /* the k-th tile handed out is (k * tile_stride) mod n_tiles; coprime to n_tiles */
     const uint32_t *tile_order; /* or, when set, tile_order[k] (n_tiles entries, a permutation) */
+    uint32_t *tile_cost;        /* when set: per tile, how many of its pixels recursed (a root with children), written when the frame is folded */
     /* the breadth-first walk's scratch (scenes with KernelScene::bfs_walk): per wave of the grid two level lists of bfs_items_cap
      * records (two words each) and a job list of bfs_jobs_cap records, one after the other */
     uint32_t *bfs_scratch;

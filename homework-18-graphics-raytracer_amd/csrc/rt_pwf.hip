@@ -981,7 +981,7 @@ __global__ __launch_bounds__(PA_THREADS, BFS ? 2 : PA_MIN_WAVES) void pwf_kernel
 #else
         for (uint32_t e0 = threadIdx.x >> 6; e0 < n_started; e0 += PA_WAVES * 4u) {
 #endif
-            uint32_t id[4], slot[4];
+            uint32_t id[4], slot[4], tile_of[4];
             uint4 ra[4], rb[4];
             bool live[4];
 #pragma unroll
@@ -989,8 +989,10 @@ __global__ __launch_bounds__(PA_THREADS, BFS ? 2 : PA_MIN_WAVES) void pwf_kernel
                 const uint32_t e = e0 + j * PA_WAVES;
                 live[j] = false;
                 id[j] = slot[j] = 0u;
+                tile_of[j] = 0xffffffffu;
                 if (e < n_started) {
                     const uint32_t tile = tile_list[e * 2u], base = tile_list[e * 2u + 1u];
+                    tile_of[j] = tile;
                     const uint32_t first_slot = tile * 64u;
                     const uint32_t nv = total_slots - first_slot < 64u ? total_slots - first_slot : 64u;
                     live[j] = lane < nv;
@@ -1001,6 +1003,13 @@ __global__ __launch_bounds__(PA_THREADS, BFS ? 2 : PA_MIN_WAVES) void pwf_kernel
                     ra[j] = nodes[pa_entry(id[j], 2u)];
                     rb[j] = make_uint4(0u, 0u, PW_FINAL, PW_NO_CHILD);
                     if (fold_level[id[j]] != 0xffu) rb[j] = nodes[pa_entry(id[j], 2u) + PA_F(1u)]; /* else complete as it stands: no second field */
+                }
+            }
+            if (pp.tile_cost != nullptr) { /* what the tile cost, roughly: how many of its pixels recursed */
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const unsigned long long deep = __builtin_amdgcn_ballot_w64(live[j] && rb[j].z != PW_FINAL);
+                    if (lane == 0u && tile_of[j] != 0xffffffffu) pp.tile_cost[tile_of[j]] = (uint32_t)__builtin_popcountll(deep);
                 }
             }
             uint4 cr4[4], cf4[4];

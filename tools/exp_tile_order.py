@@ -1,82 +1,62 @@
 #!/usr/bin/env python3
-"""Experiment: how much would a better tile order buy the persistent kernel?  The orders tried: the ideal one (tiles by
-descending cast count, taken from the CPU oracle's per-pixel counts), orders a cheap probe could produce (the centre
-pixel's cast count, capped or not; the material its primary ray hits), ascending, and plain image order — handed to the
-kernel through the diagnostic hook rt_diag_set_tile_order.  Results: profiles/README.md."""
+"""Experiment: the tiles of the Whitted frame handed out DEAREST FIRST.  The persistent kernel records, per tile, how many of its
+pixels recursed (rt_diag_set_tile_cost); sorted by that, descending, the order goes back in (rt_diag_set_tile_order): a workgroup's
+own tiles are then the dear half, dealt round-robin, and the frame-wide counter ends with the cheapest tiles.
+
+    python tools/exp_tile_order.py [--worlds 1 8] [--frames 200]
+"""
+import argparse
 import ctypes as C
 import sys
-import statistics
+import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import numpy as np
-import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
 
-import homework_18_graphics_raytracer_amd as rt
-from homework_18_graphics_raytracer_amd import _capi
-import _oracle
+import homework_18_graphics_raytracer_amd as rt  # noqa: E402
+from homework_18_graphics_raytracer_amd import _capi  # noqa: E402
 
-W, H, D = 1920, 1080, 8
-world = rt.reference_world(); cam = rt.reference_camera(); scene = rt.Scene(world)
-frame = rt.Frame.full(W, H, D)
+ap = argparse.ArgumentParser()
+ap.add_argument("--worlds", type=int, nargs="+", default=[1, 8])
+ap.add_argument("--frames", type=int, default=200)
+a = ap.parse_args()
 lib = _capi.amd_lib()
 lib.rt_diag_set_tile_order.argtypes = [C.c_void_p]
-ol = _oracle.lib()
-ol.orc_render_whitted_counts.argtypes = [C.POINTER(_capi.SceneDesc), C.POINTER(_capi.Camera), C.POINTER(_capi.Frame), C.c_void_p, C.c_void_p, C.c_int]
-img = np.zeros((H, W, 3), np.float32); cnt = np.zeros((H, W), np.uint32)
-desc = world.desc()
-ol.orc_render_whitted_counts(C.byref(desc), C.byref(cam), C.byref(frame), img.ctypes.data, cnt.ctypes.data, 0)
-# tile t = 64 consecutive slots: 8-row bands, column-major inside a band
-bands = H // 8
-cost = cnt[: bands * 8].reshape(bands, 8, W // 8, 8).sum(axis=(1, 3)).reshape(-1)  # tile = band * (W/8) + col block
-n_tiles = (W * H + 63) // 64
-assert cost.size == n_tiles
-# heuristic: the material the tile's centre pixel sees first (one primary cast per tile)
-from homework_18_graphics_raytracer_amd._capi import Material
-mats = [desc.materials[i] for i in range(desc.n_materials)]
-weight = np.zeros(n_tiles, np.int64)
-ray = _oracle.OrcRay(); hit = _oracle.OrcHit(); clip = (C.c_float * 2)()
-tw = W // 8
-for t in range(n_tiles):
-    band, cb = divmod(t, tw)
-    x, y = cb * 8 + 4, band * 8 + 4
-    ol.orc_clip(W, H, x, y, clip)
-    ol.orc_shoot(C.byref(cam), clip, C.byref(ray))
-    if ol.orc_cast(C.byref(desc), C.byref(ray), C.byref(hit)):
-        m = mats[hit.object_index]
-        weight[t] = 1 + (8 if m.transparency > 0 else 0) + (4 if m.shiness > 0 else 0)
-print("classes", np.unique(weight, return_counts=True))
-stride_perm = (np.arange(n_tiles, dtype=np.int64) * int(n_tiles * 0.6180339887) ) % n_tiles  # not exactly coprime-corrected; fine for the experiment
-centre = cnt[4:bands * 8:8, 4::8].reshape(-1).astype(np.int64)  # casts of each tile's centre pixel
-def by_key(key):
-    return np.array(sorted(range(n_tiles), key=lambda t: (-key[t], (t * 20023) % n_tiles)), dtype=np.uint32)
-orders = {
-    "centre casts, capped at 6": by_key(np.minimum(centre, 6)),
-    "centre casts, capped at 12": by_key(np.minimum(centre, 12)),
-    "centre casts, exact": by_key(centre),
-    "centre-pixel material class": np.array(sorted(range(n_tiles), key=lambda t: (-weight[t], (t * 20023) % n_tiles)), dtype=np.uint32),
-    "stride (default)": None,
-    "cost descending": np.argsort(-cost.astype(np.int64), kind="stable").astype(np.uint32),
-    "cost ascending": np.argsort(cost.astype(np.int64), kind="stable").astype(np.uint32),
-    "image order": np.arange(n_tiles, dtype=np.uint32),
-}
-out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-ref = None
-for name, order in orders.items():
-    d_order = torch.from_numpy(order.astype(np.int32)).cuda() if order is not None else None
-    lib.rt_diag_set_tile_order(C.c_void_p(d_order.data_ptr()) if d_order is not None else None)
-    ts = []
-    for r in range(7):
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+lib.rt_diag_set_tile_cost.argtypes = [C.c_void_p]
+scene = rt.Scene(rt.reference_world())
+cam = rt.reference_camera()
+W, H, D = 1920, 1080, 8
+for world in a.worlds:
+    frame = rt.Frame.full(W, H, D) if world == 1 else rt.Frame.rows_of_rank(W, H, D, 0, world)
+    out = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
+    n_tiles = (frame.rows * frame.cols + 63) // 64
+
+    def timed(n):
         for _ in range(5):
             rt.render_whitted(scene, cam, frame, out=out)
-        e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 5)
-    same = True if ref is None else torch.equal(out.view(torch.int32), ref.view(torch.int32))
-    if ref is None:
-        ref = out.clone()
-    print(f"{name:20s} median {statistics.median(ts):.4f} ms  min {min(ts):.4f} ms  identical {same}")
-lib.rt_diag_set_tile_order(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            rt.render_whitted(scene, cam, frame, out=out)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / n
+
+    base = timed(a.frames)
+    ref = out.clone()
+    cost = torch.zeros(n_tiles, dtype=torch.int32, device="cuda")
+    lib.rt_diag_set_tile_cost(C.c_void_p(cost.data_ptr()))
+    rt.render_whitted(scene, cam, frame, out=out)
+    torch.cuda.synchronize()
+    lib.rt_diag_set_tile_cost(None)
+    hist = torch.bincount(cost.clamp(0, 64), minlength=65).cpu().tolist()
+    for name, order in (("dearest first", torch.argsort(cost, descending=True, stable=True)),
+                        ("dearest first, equal costs scattered", torch.argsort(cost.to(torch.int64) * n_tiles + (torch.arange(n_tiles, device="cuda") * 20021) % n_tiles, descending=True)),
+                        ("cheapest first", torch.argsort(cost, descending=False, stable=True))):
+        order = order.to(torch.int32).contiguous()
+        lib.rt_diag_set_tile_order(C.c_void_p(order.data_ptr()))
+        ms = timed(a.frames)
+        same = torch.equal(out.view(torch.int32), ref.view(torch.int32))
+        lib.rt_diag_set_tile_order(None)
+        print(f"share 1/{world}: {name}: {ms:.4f} ms per frame against {base:.4f} in the golden-section order ({base / ms:.3f}x), frame identical: {same}", flush=True)
+    print(f"share 1/{world}: tiles with 0 / 1-63 / 64 recursing pixels: {hist[0]} / {sum(hist[1:64])} / {hist[64]} of {n_tiles}", flush=True)
