@@ -271,7 +271,8 @@ def share_timing(scene, camera, width, height, depth, steps):
     from homework_18_graphics_raytracer_amd import dist as rtdist
 
     out = {"note": "predicted from one GPU, not a scaling measurement: this GPU's time for rank 0's share of an N-rank job "
-                   "(interleaved rows, no gather); speedup_if_all_ranks_alike = whole frame / share", "shares": {}}
+                   "(interleaved rows, no gather); speedup_if_all_ranks_alike = whole frame, one after the other / share; four_in_flight: as this script "
+                   "renders a share for N > 1 (dist.FramePipeline(in_flight=4), each launch on a quarter of the device)", "shares": {}}
 
     def whitted_ms(frame):
         band = torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda")
@@ -299,14 +300,35 @@ def share_timing(scene, camera, width, height, depth, steps):
         rng.close()
         return dt
 
+    def whitted_in_flight_ms(frame, in_flight=4):
+        """As this script renders a share for N > 1: `in_flight` frames at once, one per stream, each launch on its part of the device."""
+        bands = [torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda") for _ in range(in_flight)]
+        rt.set_option("RT_AMD_WF_SHARE", in_flight)
+        try:
+            streams, _ = rtdist.choose_streams(lambda i: rt.render_whitted(scene, camera, frame, out=bands[i]), in_flight)
+
+            def run(n):
+                for k in range(n):
+                    with torch.cuda.stream(streams[k % in_flight]):
+                        rt.render_whitted(scene, camera, frame, out=bands[k % in_flight])
+                torch.cuda.synchronize()
+
+            run(2 * in_flight)
+            n = max(4 * steps, 16 * in_flight)
+            t0 = time.perf_counter()
+            run(n)
+            return (time.perf_counter() - t0) * 1e3 / n
+        finally:
+            rt.set_option("RT_AMD_WF_SHARE", None)
+
     whole = rt.Frame.full(width, height, depth)
     w1, d1 = whitted_ms(whole), dof_ms_per_epoch(whole)
     out["whole_frame"] = {"whitted_ms_per_frame": round(w1, 4), "dof_ms_per_epoch": round(d1, 4)}
     for n in (2, 4, 8):
         f = rtdist.shard_frame(width, height, depth, 0, n)
-        w, d = whitted_ms(f), dof_ms_per_epoch(f)
-        out["shares"][f"1/{n}"] = {"whitted_ms_per_frame": round(w, 4), "dof_ms_per_epoch": round(d, 4),
-                                    "speedup_if_all_ranks_alike": {"whitted": round(w1 / w, 2), "dof": round(d1 / d, 2)}}
+        w, d, w4 = whitted_ms(f), dof_ms_per_epoch(f), whitted_in_flight_ms(f)
+        out["shares"][f"1/{n}"] = {"whitted_ms_per_frame": round(w, 4), "whitted_ms_per_frame_four_in_flight": round(w4, 4), "dof_ms_per_epoch": round(d, 4),
+                                    "speedup_if_all_ranks_alike": {"whitted": round(w1 / w, 2), "whitted_four_in_flight": round(w1 / w4, 2), "dof": round(d1 / d, 2)}}
     return out
 
 
@@ -455,11 +477,19 @@ def main() -> int:
     # ... and a rank has several frames of the sequence in flight, one per stream: a share of a frame ends on the critical path of
     # its deepest pixels with most of the GPU idle.  One rank (the headline): one frame after the other.
     in_flight = 1 if not distributed else (args.frames_in_flight if args.frames_in_flight > 0 else (1 if world_size == 1 else 4))
-    pipe = rtdist.FramePipeline(W, H, D, rank, world_size, in_flight=in_flight) if distributed else None
+    device_share = in_flight if in_flight >= 3 else 1
+    chosen, calibration = None, None
+    if distributed and in_flight > 1:  # streams on which the frames in flight do run side by side (dist.choose_streams says why)
+        scratch = [torch.empty((frame.rows, frame.cols, 3), dtype=torch.float32, device="cuda") for _ in range(in_flight)]
+        if device_share > 1:
+            rt.set_option("RT_AMD_WF_SHARE", device_share)
+        chosen, calibration = rtdist.choose_streams(lambda i: rt.render_whitted(scene, camera, frame, out=scratch[i]), in_flight)
+        rt.set_option("RT_AMD_WF_SHARE", None)
+        del scratch
+    pipe = rtdist.FramePipeline(W, H, D, rank, world_size, in_flight=in_flight, streams=chosen) if distributed else None
     # from three in flight each launch takes its part of the device's workgroups, so that the frames run side by side instead of one
     # behind the other's tail (RT_AMD_WF_SHARE; profiles/r04_frames_in_flight.txt: a 1/8 share 0.168 -> 0.153 ms per frame with four,
     # and the larger shares, which four whole-device launches in flight would slow down, gain too)
-    device_share = in_flight if in_flight >= 3 else 1
     step_index = [0]
 
     def step(ev0=None, ev1=None):
@@ -560,7 +590,7 @@ def main() -> int:
                             f"3 lights), {W}x{H}, depth {D}, Whitted pass, 1 spp",
                 "width": W, "height": H, "max_depth": D,
                 "tiling": f"interleaved rows over {world_size} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frames' rendering" if distributed else ""),
-                "frames_in_flight": in_flight, "device_share_per_launch": f"1/{device_share}",
+                "frames_in_flight": in_flight, "device_share_per_launch": f"1/{device_share}", "stream_sets_tried_ms_per_frame": calibration,
                 "kernel_variant": "persistent-wavefront" if variant & 16 else ("per-pixel, LDS-staged triangles" if variant & 1 else "per-pixel, scalar triangle fetches"),
             },
             "casts_per_frame": casts_per_frame,

@@ -250,6 +250,39 @@ def finish_frame_sharded(band, height: int, rank: int, world: int, dst: int = 0,
     return gather_frame(encode_srgb8_band(band), height, rank, world, dst=dst, group=group, staging=staging), divisor
 
 
+def choose_streams(render, in_flight: int, attempts: int = 4, frames_per_stream: int = 6):
+    """`in_flight` torch streams on which frames in flight actually run side by side.
+
+    A process's HIP streams share a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and which queues run concurrently is the
+    driver's business, not the caller's: of the sets of four streams a process makes, about one in five renders four frames in flight
+    SLOWER than one after the other (profiles/r04_frames_in_flight.txt, tools/exp_queue_mapping.py) — costly when each launch has been
+    given a quarter of the device.  So: make a set, time a few frames on it (`render(i)` issues one frame on the current stream into
+    buffer i of `in_flight`), keep the best of `attempts` sets.  Returns (streams, ms_per_frame of every attempt)."""
+    import time
+
+    import torch
+
+    best, best_ms, seen = None, None, []
+    for _ in range(max(1, attempts)):
+        streams = [torch.cuda.Stream() for _ in range(in_flight)]
+
+        def run(n):
+            for k in range(n):
+                with torch.cuda.stream(streams[k % in_flight]):
+                    render(k % in_flight)
+            torch.cuda.synchronize()
+
+        run(2 * in_flight)  # each stream's workspace exists
+        n = frames_per_stream * in_flight
+        t0 = time.perf_counter()
+        run(n)
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        seen.append(round(ms, 4))
+        if best_ms is None or ms < best_ms:
+            best, best_ms = streams, ms
+    return best, seen
+
+
 class FramePipeline:
     """A sequence of frames with the gather of frame k overlapped with the rendering of the frames behind it.
 
@@ -274,7 +307,8 @@ class FramePipeline:
         last = pipe.finish()                        # frame n-1 assembled (rank 0); the ones before it have been assembled too
     """
 
-    def __init__(self, width: int, height: int, max_depth: int, rank: int, world: int, dst: int = 0, group=None, device="cuda", in_flight: int = 1):
+    def __init__(self, width: int, height: int, max_depth: int, rank: int, world: int, dst: int = 0, group=None, device="cuda", in_flight: int = 1,
+                 streams=None):
         import torch
 
         self.frame = shard_frame(width, height, max_depth, rank, world)
@@ -287,7 +321,10 @@ class FramePipeline:
         self._staging = [torch.empty((world, self.max_rows, width, 3), dtype=torch.float32, device=device) for _ in range(self.slots)] if rank == dst else None
         self._work = [None] * self.slots
         on_gpu = torch.device(device).type == "cuda"
-        self._streams = [torch.cuda.Stream() for _ in range(self.in_flight)] if self.in_flight > 1 and on_gpu else None
+        self._streams = None
+        if self.in_flight > 1 and on_gpu:  # the caller's (choose_streams), or fresh ones
+            self._streams = list(streams) if streams is not None else [torch.cuda.Stream() for _ in range(self.in_flight)]
+            assert len(self._streams) == self.in_flight
         self._last = -1        # the last frame submitted
         self._assembled = -1   # the last frame assembled
 

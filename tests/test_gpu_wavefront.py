@@ -217,6 +217,29 @@ def test_frames_in_flight_side_by_side_on_parts_of_the_device(ref, share):
             assert int(cnt.item()) == 2 * len(streams) * want[k][1]
 
 
+def test_choose_streams_returns_streams_that_render_the_same_frame(ref):
+    """dist.choose_streams (bench.py for N > 1): a few sets of streams timed with frames in flight, the best kept; whatever set it is,
+    the frames rendered on it are the oracle's."""
+    import torch
+
+    from homework_18_graphics_raytracer_amd import dist as rtdist
+
+    world, cam, scene = ref
+    f = rt.Frame.rows_of_rank(480, 270, 8, 0, 2)
+    bands = [torch.zeros((f.rows, f.cols, 3), dtype=torch.float32, device="cuda") for _ in range(3)]
+    with rt.options(RT_AMD_WF_SHARE=3):
+        streams, tried = rtdist.choose_streams(lambda i: rt.render_whitted(scene, cam, f, out=bands[i]), 3, attempts=2, frames_per_stream=2)
+        assert len(streams) == 3 and len(tried) == 2 and all(t > 0 for t in tried)
+        for b in bands:
+            b.zero_()
+        for i, st in enumerate(streams):
+            rt.render_whitted(scene, cam, f, out=bands[i], stream=st)
+        torch.cuda.synchronize()
+    want, _ = _oracle.render_whitted(world.desc(), cam, f)
+    for b in bands:
+        assert np.array_equal(b.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
 def test_two_host_threads_render_concurrently_with_profiling_on(ref):
     """rt_render_whitted from two HOST threads, each on its own stream, with the profiling hooks enabled: the settings
     are atomics, the workspaces are created under the scene's lock and a call's event pair is thread-local, so both
