@@ -20,17 +20,18 @@ namespace rt {
  * kilobyte more often than not.
  *
  *   levels  the nodes are numbered in LEVEL ORDER (KernelScene::bfs_nodes): an inner node's children are a range of the same array, so
- *           "descend into this node" is one record.  Level 0: every active ray x the top-level nodes.  Per pair: the node's record
- *           (six 16-byte loads per lane, all in flight together), the ray from the wave's LDS table, cluster_skippable_lane's test.  A
+ *           "descend into this node" is one record.  Level 0: every active ray x the top-level nodes.  Per pair: three 16-byte pieces of
+ *           the node (bounding sphere, counts, the first plane direction or the cone; a node with more plane directions has the others
+ *           fetched when a lane gets that far), the ray from the wave's LDS table, cluster_skippable_lane's test.  A
  *           node the ray may hit: an inner node becomes a record of the next level, a LEAF a JOB — flagged BAND when the ray's line
  *           misses the leaf's sphere and the leaf was only kept because the ray is nearly parallel to one of its planes (one of
  *           SEVERAL: when the leaf has one plane direction all its triangles are nearly parallel to the ray, and it is a plain job).
- *   jobs    per pair: the triangle's plane and bounding sphere from DevTriHead (two 16-byte loads per lane, issued one pass ahead, the
- *           records two), then the reference's single-triangle test (main.rs:184-224) in the reference's operation order: culling,
+ *   jobs    per pair: the triangle's plane and bounding sphere (two 16-byte loads per lane, issued a group of passes ahead, the
+ *           records two groups), then the reference's single-triangle test (main.rs:184-224) in the reference's operation order: culling,
  *           exclusion, t, `t <= 0`, the conservative bounding-sphere rejection of rt_cast_asm.h — and, for the few pairs that get that
- *           far (the CANDIDATES, collected in LDS and taken 64 at a time), the whole test once more with the three signed areas.  An accepted pair does ONE ds_min_u64 of
- *           (bits(t) << 32 | ~index) on its ray's slot: among all accepted candidates of a cast the reference ends with the smallest t
- *           and, among equal t, the LAST index (main.rs:229-233) — as long as no accepted t is NaN.
+ *           far (the CANDIDATES, collected in LDS and taken 64 at a time), the whole test once more with the three signed areas.  An
+ *           accepted pair does ONE ds_min_u64 of (bits(t) << 32 | ~index) on its ray's slot: among all accepted candidates of a cast
+ *           the reference ends with the smallest t and, among equal t, the LAST index (main.rs:229-233) — as long as no accepted t is NaN.
  *   band jobs  (kept in a region of their own): the node rejection's argument is made triangle by triangle — the ray's line misses a
  *           sphere that contains the triangle's own, and the ray is not nearly parallel to THAT triangle's plane (|n . d| >= 1e-3,
  *           n . d being the very value the test computes) — so a pair of a band job only goes on to the test if its own plane is the
@@ -93,7 +94,7 @@ __device__ __forceinline__ uint2 bfs_load_record(const uint2 *p) {
     const bfs_u32x2 v = *reinterpret_cast<const __attribute__((address_space(1))) bfs_u32x2 *>(reinterpret_cast<uintptr_t>(p));
     return make_uint2(v.x, v.y);
 }
-/* a group's records sit one per lane (lanes 0 .. 4 G - 1); pass q takes records 4 q .. 4 q + 3, lane l the (l & 3)-th of them */
+/* a group's records sit one per lane (lanes 0 .. 4 G - 1); pass q takes records 4 q .. 4 q + 3, lane l the (l >> 4)-th of them */
 __device__ __forceinline__ uint2 bfs_record_of(const uint2 group, const uint32_t q, const uint32_t rec_lane) {
     const int from = (int)((4u * q + rec_lane) << 2);
     return make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)group.x), (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)group.y));
