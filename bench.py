@@ -362,7 +362,21 @@ def large_scene(camera, width, height, depth, levels=6):
         rt.render_whitted(scene, camera, frame, out=out)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
-    return {"workload": f"the reference scene around a dodecahedron of {36 * 4 ** levels} flat triangles ({desc.n_triangles} triangles, {desc.n_triangles * 128 / 1e6:.1f} MB of records), "
+    # ... and four epochs of the depth-of-field pass in one call (the one-kernel organisation with the same walk), fresh streams, after a warm one
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    warm = rt.Rng(frame)
+    rt.render_distributed(scene, camera, frame, warm, 1, accum=accum)
+    torch.cuda.synchronize()
+    warm.close()
+    rng = rt.Rng(frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rt.render_distributed(scene, camera, frame, rng, 4, accum=accum)
+    torch.cuda.synchronize()
+    dof_ms = (time.perf_counter() - t0) * 1e3 / 4
+    rng.close()
+    return {"dof_ms_per_epoch": round(dof_ms, 2), "dof_Msamples_per_s": round(width * height / dof_ms / 1e3, 2),
+            "workload": f"the reference scene around a dodecahedron of {36 * 4 ** levels} flat triangles ({desc.n_triangles} triangles, {desc.n_triangles * 128 / 1e6:.1f} MB of records), "
                         f"{width}x{height}, depth {depth}, Whitted pass, breadth-first walk of the node tree",
             "ms_per_frame": round(ms, 3), "Mrays_per_s": round(casts / ms / 1e3, 2), "casts_per_frame": casts,
             "algorithmic_T_triangle_tests_per_s": round(casts * desc.n_triangles / ms / 1e9, 2),
