@@ -46,10 +46,16 @@ namespace rt {
  * in flight and the records of the one after that are on their way — a wave alone on its SIMD (the tail of a frame, the one heavy
  * wave-cast of a tile of grazing rays) is otherwise one memory round trip per pass.  The kernel that uses this walk therefore gives
  * itself 256 VGPRs and a whole CU's LDS (rt_pwf.hip: one workgroup per CU). */
+#ifndef RT_BFS_LEVEL_GROUP
 #define RT_BFS_LEVEL_GROUP 4u /* passes per group of the level loop: 16 records */
+#endif
+#ifndef RT_BFS_PAIR_GROUP
 #define RT_BFS_PAIR_GROUP 4u  /* of the job loop */
+#endif
+#ifndef RT_BFS_BAND_GROUP
 #define RT_BFS_BAND_GROUP 8u  /* of the band-job loop: 32 records */
-#define RT_BFS_CANDIDATES (64u + 64u * RT_BFS_BAND_GROUP) /* a group may add 64 per pass; drained between groups down to 64 at most */
+#endif
+#define RT_BFS_CANDIDATES (64u + 64u * (RT_BFS_BAND_GROUP > RT_BFS_PAIR_GROUP ? RT_BFS_BAND_GROUP : RT_BFS_PAIR_GROUP)) /* a group may add 64 per pass; drained between groups down to 64 at most */
 struct BfsLds {
     uint32_t nan_last[64];      /* per ray: 1 + the LAST triangle accepted with a NaN distance (0: none) */
     unsigned long long key[64]; /* per ray: the smallest (bits(t) << 32 | ~triangle) accepted so far */
