@@ -642,8 +642,8 @@ def main() -> int:
     # of its deepest pixels while most of the GPU idles; independent frames fill that.  Same pixels.
     pipelined = None
     if not args.no_pipelined and in_flight == 1:  # (with several frames in flight the headline already is this)
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         bands2 = [torch.empty_like(band), torch.empty_like(band)]
+        streams, _ = rtdist.choose_streams(lambda i: rt.render_whitted(scene, camera, frame, out=bands2[i]), 2, attempts=3, frames_per_stream=4)  # (a pair that does overlap)
         count2 = torch.zeros(1, dtype=torch.int64, device="cuda")
         pipe2 = rtdist.FramePipeline(W, H, D, rank, world_size) if distributed else None
 
